@@ -1,0 +1,298 @@
+"""ctypes binding of the C ABI in include/heat_amd.h.
+
+``HeatBatch`` mirrors, at batch level, the reference's ``ThermalModel`` contract
+(src/model.rs:188-428): ``HeatBatch(md)`` ≙ ``ThermalModel::new`` + ``allocate_memory``,
+``HeatBatch.march(state, weather)`` ≙ ``ThermalModel::march``. Errors become ``HeatError``
+(the reference returns ``Err(String)`` or panics).
+
+The library is loaded from ``heat_amd/lib/libheat_amd.so``. If it is missing this module
+raises: the HIP path is the only path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_d = C.c_double
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class HeatError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("heat_amd error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+class Cavity(C.Structure):
+    _fields_ = [("thickness", _d), ("height", _d), ("angle", _d), ("eout", _d), ("ein", _d),
+                ("gas", C.c_int32), ("reserved", C.c_int32)]
+
+
+CAVITY_DTYPE = np.dtype([("thickness", "f8"), ("height", "f8"), ("angle", "f8"), ("eout", "f8"),
+                         ("ein", "f8"), ("gas", "i4"), ("reserved", "i4")])
+
+
+class Weather(C.Structure):
+    _fields_ = [("dry_bulb", _d), ("wind_direction", _d), ("wind_speed", _d)]
+
+
+class Desc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("reserved", C.c_int32),
+        ("n_surfaces", C.c_int64), ("n_zones", C.c_int64), ("n_cavities", C.c_int64), ("n_state", C.c_int64),
+        ("dt", _d),
+        ("node_offset", _i64p), ("mass", _dp), ("uvalue", _dp), ("seg_cavity", _i32p),
+        ("front_alpha", _dp), ("back_alpha", _dp), ("cavities", C.POINTER(Cavity)),
+        ("front_kind", _i32p), ("back_kind", _i32p), ("front_zone", _i32p), ("back_zone", _i32p),
+        ("front_ambient", _dp), ("back_ambient", _dp), ("front_emissivity", _dp), ("back_emissivity", _dp),
+        ("area", _dp), ("perimeter", _dp), ("cos_tilt", _dp), ("normal_x", _dp), ("normal_y", _dp),
+        ("wind_modifier", _dp), ("front_hs_fix", _dp), ("back_hs_fix", _dp),
+        ("first_node_slot", _i64p), ("hs_front_slot", _i64p), ("hs_back_slot", _i64p),
+        ("flow_front_slot", _i64p), ("flow_back_slot", _i64p), ("solar_front_slot", _i64p),
+        ("solar_back_slot", _i64p), ("ir_front_slot", _i64p), ("ir_back_slot", _i64p),
+        ("zone_volume", _dp), ("zone_slot", _i64p),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("force_general", C.c_int32), ("nodes_per_lane", C.c_int32),
+                ("use_graph", C.c_int32), ("stream", C.c_void_p), ("n_ranks", C.c_int32), ("rank", C.c_int32)]
+
+
+# Every symbol include/heat_amd.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = [
+    ("heat_batch_create", C.c_int, [C.POINTER(Desc), C.POINTER(_H)]),
+    ("heat_batch_create_ex", C.c_int, [C.POINTER(Desc), C.POINTER(Options), C.POINTER(_H)]),
+    ("heat_batch_destroy", None, [_H]),
+    ("heat_batch_upload_state", C.c_int, [_H, _dp, C.c_size_t]),
+    ("heat_batch_download_state", C.c_int, [_H, _dp, C.c_size_t]),
+    ("heat_batch_upload_inputs", C.c_int, [_H, _dp, C.c_size_t]),
+    ("heat_batch_march", C.c_int, [_H, _dp, C.c_size_t, C.POINTER(Weather), C.c_int32, _dp, _dp]),
+    ("heat_batch_march_resident", C.c_int, [_H, C.POINTER(Weather), C.c_int32, _dp, _dp]),
+    ("heat_batch_synchronize", C.c_int, [_H]),
+    ("heat_batch_set_weather", C.c_int, [_H, C.POINTER(Weather), C.c_int32, _dp, _dp]),
+    ("heat_batch_step_surfaces", C.c_int, [_H, C.c_int32]),
+    ("heat_batch_step_zones", C.c_int, [_H, C.c_void_p, C.c_int32]),
+    ("heat_batch_zone_partials", C.c_void_p, [_H]),
+    ("heat_batch_n_surfaces", C.c_int64, [_H]),
+    ("heat_batch_n_nodes", C.c_int64, [_H]),
+    ("heat_batch_n_zones", C.c_int64, [_H]),
+    ("heat_batch_algorithmic_bytes", C.c_int64, [_H]),
+    ("heat_batch_nomass_iterations", C.c_int64, [_H]),
+    ("heat_batch_class_counts", C.c_int, [_H, _i64p]),
+    ("heat_batch_set_timing", C.c_int, [_H, C.c_int32]),
+    ("heat_batch_get_timing", C.c_int, [_H, _dp, _dp, _i64p]),
+    ("heat_last_error", C.c_char_p, []),
+    ("heat_amd_abi_version", C.c_int, []),
+]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def build_library(force=False):
+    return _build.build(force=force)
+
+
+def load_library():
+    """Loads libheat_amd.so and binds every declared symbol. Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "heat_amd: %s is missing. Build it with `python -m heat_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        f = getattr(L, name)  # AttributeError if the library does not export it
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise HeatError(rc, load_library().heat_last_error().decode("utf-8", "replace"))
+
+
+def as_weather(weather):
+    """[n,3] array (dry bulb C, wind direction RADIANS, wind speed m/s) -> ctypes array."""
+    w = np.ascontiguousarray(weather, dtype=np.float64).reshape(-1, 3)
+    arr = (Weather * len(w))()
+    if len(w):
+        C.memmove(arr, w.ctypes.data, w.nbytes)
+    return arr, len(w)
+
+
+_F64 = ["mass", "uvalue", "front_alpha", "back_alpha", "front_ambient", "back_ambient", "front_emissivity",
+        "back_emissivity", "area", "perimeter", "cos_tilt", "normal_x", "normal_y", "wind_modifier", "zone_volume"]
+_I32 = ["front_kind", "back_kind", "front_zone", "back_zone"]
+_I64 = ["node_offset", "first_node_slot", "hs_front_slot", "hs_back_slot", "flow_front_slot", "flow_back_slot",
+        "solar_front_slot", "solar_back_slot", "ir_front_slot", "ir_back_slot", "zone_slot"]
+
+
+def make_desc(md):
+    """Builds a heat_batch_desc from the model dict (heat_amd.modeldict). Returns (desc, keepalive)."""
+    keep = {}
+    d = Desc()
+    d.abi_version = 1
+    d.n_surfaces = int(md["n_surfaces"])
+    d.n_zones = int(md["n_zones"])
+    d.n_state = int(md["n_state"])
+    d.dt = float(md["dt"])
+    for k in _F64:
+        a = np.ascontiguousarray(md[k], dtype=np.float64)
+        keep[k] = a
+        setattr(d, k, a.ctypes.data_as(_dp))
+    for k in _I32:
+        a = np.ascontiguousarray(md[k], dtype=np.int32)
+        keep[k] = a
+        setattr(d, k, a.ctypes.data_as(_i32p))
+    for k in _I64:
+        a = np.ascontiguousarray(md[k], dtype=np.int64)
+        keep[k] = a
+        setattr(d, k, a.ctypes.data_as(_i64p))
+    if md.get("front_hs_fix") is not None:
+        for k in ("front_hs_fix", "back_hs_fix"):
+            a = np.ascontiguousarray(md[k], dtype=np.float64)
+            keep[k] = a
+            setattr(d, k, a.ctypes.data_as(_dp))
+    cav = md.get("cavities")
+    if cav is not None and len(cav) and md.get("seg_cavity") is not None:
+        sc = np.ascontiguousarray(md["seg_cavity"], dtype=np.int32)
+        cv = np.zeros(len(cav), dtype=CAVITY_DTYPE)
+        for f in ("thickness", "height", "angle", "eout", "ein", "gas"):
+            cv[f] = cav[f]
+        keep["seg_cavity"] = sc
+        keep["cavities"] = cv
+        d.seg_cavity = sc.ctypes.data_as(_i32p)
+        d.cavities = cv.ctypes.data_as(C.POINTER(Cavity))
+        d.n_cavities = len(cv)
+    return d, keep
+
+
+class HeatBatch:
+    """Device-resident batch of surfaces + zones (≙ ThermalModel, src/model.rs:54-77)."""
+
+    def __init__(self, md, device=-1, force_general=False, nodes_per_lane=0, use_graph=False, stream=None,
+                 n_ranks=1, rank=0):
+        self._L = load_library()
+        self._h = _H()
+        desc, keep = make_desc(md)
+        opt = Options()
+        opt.device = device
+        opt.force_general = 1 if force_general else 0
+        opt.nodes_per_lane = nodes_per_lane
+        opt.use_graph = 1 if use_graph else 0
+        opt.stream = stream
+        opt.n_ranks = n_ranks
+        opt.rank = rank
+        _check(self._L.heat_batch_create_ex(C.byref(desc), C.byref(opt), C.byref(self._h)))
+        self.n_state = int(md["n_state"])
+        self.n_zones = int(md["n_zones"])
+        self.n_surfaces = int(md["n_surfaces"])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.heat_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @staticmethod
+    def _state_ptr(state):
+        assert state.dtype == np.float64 and state.flags.c_contiguous
+        return state.ctypes.data_as(_dp)
+
+    @staticmethod
+    def _opt(a):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data_as(_dp)
+
+    def upload_state(self, state):
+        _check(self._L.heat_batch_upload_state(self._h, self._state_ptr(state), state.size))
+
+    def upload_inputs(self, state):
+        _check(self._L.heat_batch_upload_inputs(self._h, self._state_ptr(state), state.size))
+
+    def download_state(self, state):
+        _check(self._L.heat_batch_download_state(self._h, self._state_ptr(state), state.size))
+
+    def march(self, state, weather, zone_a0=None, zone_b0=None):
+        """≙ ThermalModel::march: len(weather) sub-timesteps, in place on ``state``."""
+        w, n = as_weather(weather)
+        a0, pa = self._opt(zone_a0)
+        b0, pb = self._opt(zone_b0)
+        _check(self._L.heat_batch_march(self._h, self._state_ptr(state), state.size, w, n, pa, pb))
+
+    def march_resident(self, weather, zone_a0=None, zone_b0=None):
+        w, n = as_weather(weather)
+        a0, pa = self._opt(zone_a0)
+        b0, pb = self._opt(zone_b0)
+        _check(self._L.heat_batch_march_resident(self._h, w, n, pa, pb))
+
+    def synchronize(self):
+        _check(self._L.heat_batch_synchronize(self._h))
+
+    def set_weather(self, weather, zone_a0=None, zone_b0=None):
+        w, n = as_weather(weather)
+        a0, pa = self._opt(zone_a0)
+        b0, pb = self._opt(zone_b0)
+        _check(self._L.heat_batch_set_weather(self._h, w, n, pa, pb))
+
+    def step_surfaces(self, sub_step):
+        _check(self._L.heat_batch_step_surfaces(self._h, sub_step))
+
+    def step_zones(self, gathered_ptr, n_blocks):
+        _check(self._L.heat_batch_step_zones(self._h, gathered_ptr, n_blocks))
+
+    def zone_partials_ptr(self):
+        return self._L.heat_batch_zone_partials(self._h)
+
+    def set_timing(self, enabled):
+        _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))
+
+    def get_timing(self):
+        a, b, n = _d(0), _d(0), C.c_int64(0)
+        _check(self._L.heat_batch_get_timing(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    @property
+    def algorithmic_bytes(self):
+        return self._L.heat_batch_algorithmic_bytes(self._h)
+
+    @property
+    def n_nodes(self):
+        return self._L.heat_batch_n_nodes(self._h)
+
+    def nomass_iterations(self):
+        return self._L.heat_batch_nomass_iterations(self._h)
+
+    def class_counts(self):
+        c = (C.c_int64 * 4)()
+        _check(self._L.heat_batch_class_counts(self._h, c))
+        return list(c)

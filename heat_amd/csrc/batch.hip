@@ -1,0 +1,859 @@
+// batch.hip — implementation of the C ABI declared in include/heat_amd.h.
+//
+// heat_batch_create re-orders the caller's surfaces into the lane-blocked device layout
+// (layout.hpp), heat_batch_march* drive the kernels of kernels.hip on one HIP stream.
+// There is no CPU fallback: every entry point that computes needs a HIP device and fails
+// with HEAT_E_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/heat_amd.h"
+#include "kernels.hpp"
+#include "layout.hpp"
+
+using namespace heat;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(HEAT_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    hipError_t zeros(size_t count) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemset(p, 0, count * sizeof(T));
+    }
+};
+
+constexpr int kMaxNodesGeneral = 4096;
+constexpr int kScratchArrays = 7;
+const int kFastM[3] = {4, 8, 16};
+
+}  // namespace
+
+struct heat_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_ranks = 1, rank = 0;
+    bool use_graph = false;
+
+    int64_t n_surf = 0, n_zones = 0, n_state = 0, n_nodes = 0, n_cav = 0;
+    double dt = 0;
+    int64_t algorithmic_bytes = 0;
+    int64_t class_counts[4] = {0, 0, 0, 0};
+
+    // layout
+    int n_fast_tiles[3] = {0, 0, 0};
+    DevBuf<FastTile> d_fast_tiles[3];
+    int n_gen_tiles = 0;
+    DevBuf<GeneralTile> d_gen_tiles;
+    int64_t gen_base = 0;     // first node slot of the general group
+    int64_t node_slots = 0;   // total node slots incl. padding
+
+    DevBuf<double> d_T, d_V, d_U, d_alpha_f, d_alpha_b, d_mass, d_scratch;
+    DevBuf<int32_t> d_cav_idx;
+    DevBuf<CavityDev> d_cavs;
+
+    DevBuf<int32_t> d_meta, d_front_zone, d_back_zone;
+    DevBuf<double> d_front_amb, d_back_amb, d_front_emis, d_back_emis, d_area, d_perimeter, d_cos_tilt,
+        d_nx, d_ny, d_wind_mod, d_alpha_f0, d_alpha_bn, d_hs_fix_f, d_hs_fix_b;
+    DevBuf<double> d_solar_f, d_solar_b, d_ir_f, d_ir_b;
+    DevBuf<double> d_hs;    // [hs_f | hs_b]
+    DevBuf<double> d_flow;  // [flow_f | flow_b]
+    DevBuf<int64_t> d_first_slot, d_slots;  // d_slots: 8 arrays of n_surf
+    DevBuf<int64_t> d_zone_slot, d_zone_off;
+    DevBuf<ZoneEntry> d_zone_entries;
+    DevBuf<double> d_zone_vol, d_zone_T, d_zone_a0, d_zone_b0, d_partial;
+    DevBuf<double> d_state;
+    DevBuf<StepWeather> d_weather;
+    DevBuf<int> d_step, d_flags;
+    DevBuf<unsigned long long> d_nomass_iters;
+
+    StepWeather *h_weather = nullptr;  // pinned
+    double *h_zone_ab = nullptr;       // pinned, [2][n_zones]
+    size_t weather_cap = 0;
+    int n_weather = 0;
+
+    // host copies for download (original surface order)
+    std::vector<int64_t> h_first_slot, h_node_count, h_out_slots[4], h_zone_slot_h;
+    std::vector<double> h_stage;
+
+    SurfArrays sa{};
+    NodeArrays na{};
+    SlotArrays sl{};
+
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+
+    ~heat_batch() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        if (h_weather) (void)hipHostFree(h_weather);
+        if (h_zone_ab) (void)hipHostFree(h_zone_ab);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+struct Placed {
+    int64_t s;   // original surface index
+    int n;       // node count
+    int cls;     // 0..2 fast (M = 4, 8, 16), 3 general
+    int k;       // lanes per surface (fast)
+};
+
+// Decides whether a surface can take the register-resident fast path.
+int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
+    if (opt.force_general) return 3;
+    const int64_t o = d->node_offset[s];
+    for (int i = 0; i < n; i++) {
+        if (d->mass[o + i] < kMassThreshold) return 3;                        // no-mass node
+        if (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0) return 3;  // gas cavity
+        if (i > 0 && d->front_alpha[o + i] != 0.0) return 3;                  // solar absorbed inside
+        if (i < n - 1 && d->back_alpha[o + i] != 0.0) return 3;
+    }
+    if (n < 2) return 3;
+    int M = opt.nodes_per_lane;
+    if (M == 0) {
+        const int n4 = (n + 3) / 4 * 4;
+        M = (n4 % 16 == 0) ? 16 : (n4 % 8 == 0) ? 8 : 4;
+    }
+    const int k = (n + M - 1) / M;
+    if (k > kWave) return 3;
+    return M == 4 ? 0 : (M == 8 ? 1 : 2);
+}
+
+int check_desc(const heat_batch_desc *d) {
+    if (!d) return fail(HEAT_E_INVALID_ARG, "descriptor is NULL");
+    if (d->abi_version != HEAT_AMD_ABI_VERSION)
+        return fail(HEAT_E_INVALID_ARG, "abi_version %d, library is %d", d->abi_version, HEAT_AMD_ABI_VERSION);
+    if (d->n_surfaces < 0 || d->n_zones < 0 || d->n_cavities < 0 || d->n_state < 0)
+        return fail(HEAT_E_INVALID_ARG, "negative count in descriptor");
+    if (!(d->dt > 0.0)) return fail(HEAT_E_INVALID_ARG, "dt must be positive");
+    const void *need[] = {d->node_offset, d->mass, d->uvalue, d->front_alpha, d->back_alpha, d->front_kind,
+                          d->back_kind, d->front_zone, d->back_zone, d->front_ambient, d->back_ambient,
+                          d->front_emissivity, d->back_emissivity, d->area, d->perimeter, d->cos_tilt,
+                          d->normal_x, d->normal_y, d->wind_modifier, d->first_node_slot, d->hs_front_slot,
+                          d->hs_back_slot, d->flow_front_slot, d->flow_back_slot, d->solar_front_slot,
+                          d->solar_back_slot, d->ir_front_slot, d->ir_back_slot};
+    if (d->n_surfaces > 0)
+        for (const void *p : need)
+            if (!p) return fail(HEAT_E_INVALID_ARG, "a required per-surface array is NULL");
+    if (d->n_zones > 0 && (!d->zone_volume || !d->zone_slot))
+        return fail(HEAT_E_INVALID_ARG, "zone arrays are NULL");
+    if (d->n_cavities > 0 && (!d->cavities || !d->seg_cavity))
+        return fail(HEAT_E_INVALID_ARG, "cavity arrays are NULL");
+    if ((d->front_hs_fix == nullptr) != (d->back_hs_fix == nullptr))
+        return fail(HEAT_E_INVALID_ARG, "front_hs_fix and back_hs_fix must both be given or both be NULL");
+    const int64_t ns = d->n_state;
+    auto slot_ok = [&](int64_t v) { return v >= 0 && v < ns; };
+    for (int64_t z = 0; z < d->n_zones; z++)
+        if (!slot_ok(d->zone_slot[z])) return fail(HEAT_E_SIZE, "zone %lld: slot out of range", (long long)z);
+    if (d->n_surfaces > 0 && d->node_offset[0] != 0) return fail(HEAT_E_INVALID_ARG, "node_offset[0] != 0");
+    for (int64_t s = 0; s < d->n_surfaces; s++) {
+        const int64_t n = d->node_offset[s + 1] - d->node_offset[s];
+        if (n < 1) return fail(HEAT_E_INVALID_ARG, "surface %lld has %lld nodes", (long long)s, (long long)n);
+        if (n > kMaxNodesGeneral)
+            return fail(HEAT_E_TOO_MANY_NODES, "surface %lld has %lld nodes (max %d)", (long long)s, (long long)n,
+                        kMaxNodesGeneral);
+        const int fk = d->front_kind[s], bk = d->back_kind[s];
+        if (fk == HEAT_BOUNDARY_GROUND || bk == HEAT_BOUNDARY_GROUND)
+            return fail(HEAT_E_GROUND_BOUNDARY, "surface %lld: Ground boundary is not supported (reference panics)", (long long)s);
+        if (fk < 0 || fk > 2 || bk < 0 || bk > 2)
+            return fail(HEAT_E_INVALID_ARG, "surface %lld: unknown boundary kind", (long long)s);
+        if (fk == HEAT_BOUNDARY_SPACE && (d->front_zone[s] < 0 || d->front_zone[s] >= d->n_zones))
+            return fail(HEAT_E_SIZE, "surface %lld: front zone out of range", (long long)s);
+        if (bk == HEAT_BOUNDARY_SPACE && (d->back_zone[s] < 0 || d->back_zone[s] >= d->n_zones))
+            return fail(HEAT_E_SIZE, "surface %lld: back zone out of range", (long long)s);
+        if (d->first_node_slot[s] < 0 || d->first_node_slot[s] + n > ns)
+            return fail(HEAT_E_SIZE, "surface %lld: node slots out of range", (long long)s);
+        if (!slot_ok(d->hs_front_slot[s]) || !slot_ok(d->hs_back_slot[s]) || !slot_ok(d->flow_front_slot[s]) ||
+            !slot_ok(d->flow_back_slot[s]) || !slot_ok(d->solar_front_slot[s]) || !slot_ok(d->solar_back_slot[s]) ||
+            !slot_ok(d->ir_front_slot[s]) || !slot_ok(d->ir_back_slot[s]))
+            return fail(HEAT_E_SIZE, "surface %lld: scalar slot out of range", (long long)s);
+        const int64_t o = d->node_offset[s];
+        for (int64_t i = 0; i < n; i++) {
+            const bool cav = d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0;
+            if (cav && d->seg_cavity[o + i] >= d->n_cavities)
+                return fail(HEAT_E_SIZE, "surface %lld: cavity index out of range", (long long)s);
+            if (!cav && std::isnan(d->uvalue[o + i]))
+                return fail(HEAT_E_UVALUE_NONE, "surface %lld node %lld: UValue::None", (long long)s, (long long)i);
+        }
+    }
+    return HEAT_OK;
+}
+
+int flags_to_status(int f) {
+    if (f & FLAG_NAN_HS) return fail(HEAT_N_NAN_HS, "NaN convection coefficient (reference: surface.rs:704)");
+    if (f & FLAG_NAN_NOMASS) return fail(HEAT_N_NAN_NOMASS, "NaN error in the no-mass loop (reference: surface.rs:850)");
+    if (f & FLAG_NAN_ZONE) return fail(HEAT_N_NAN_ZONE, "NaN zone temperature (reference: model.rs:417)");
+    if (f & FLAG_UNREACHABLE) return fail(HEAT_N_UNREACHABLE, "unreachable!() branch taken (NaN input)");
+    return HEAT_OK;
+}
+
+int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt) {
+    const int64_t S = d->n_surfaces, Z = d->n_zones;
+    b->n_surf = S;
+    b->n_zones = Z;
+    b->n_state = d->n_state;
+    b->n_cav = d->n_cavities;
+    b->dt = d->dt;
+    b->n_nodes = S > 0 ? d->node_offset[S] : 0;
+    b->algorithmic_bytes = 32 * b->n_nodes + (136 + 32) * S;
+
+    // ---- classify and order ----
+    std::vector<Placed> placed(S);
+    for (int64_t s = 0; s < S; s++) {
+        const int n = (int)(d->node_offset[s + 1] - d->node_offset[s]);
+        const int cls = classify(d, s, n, opt);
+        const int M = cls < 3 ? kFastM[cls] : 0;
+        placed[s] = Placed{s, n, cls, cls < 3 ? (n + M - 1) / M : 1};
+        b->class_counts[cls]++;
+    }
+    std::vector<int64_t> order(S);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        const Placed &a = placed[x], &c = placed[y];
+        if (a.cls != c.cls) return a.cls < c.cls;
+        if (a.cls < 3) return a.k < c.k;
+        return a.n < c.n;
+    });
+
+    // ---- tiles ----
+    std::vector<FastTile> fast_tiles[3];
+    std::vector<GeneralTile> gen_tiles;
+    std::vector<int64_t> dev_of(S);            // original -> device surface
+    std::vector<int64_t> node0_index(S), nodeN_index(S);  // index of first / last node in the T buffer
+    std::vector<int64_t> orig_of(S);
+    int64_t node_cursor = 0, scratch_cursor = 0;
+    int64_t dcur = 0;
+    size_t pos = 0;
+    struct NodeMap { int64_t base; int Lk; int k; int M; int g; };  // per device surface
+    std::vector<NodeMap> nmap(S);
+    while (pos < (size_t)S) {
+        const Placed &p0 = placed[order[pos]];
+        if (p0.cls < 3) {
+            const int M = kFastM[p0.cls], k = p0.k;
+            const int Gmax = kWave / k, Lk = Gmax * k;
+            size_t end = pos;
+            while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].k == k &&
+                   (int)(end - pos) < Gmax)
+                end++;
+            FastTile t;
+            t.node_base = node_cursor;
+            t.surf_base = (int32_t)dcur;
+            t.k = (int16_t)k;
+            t.G = (int16_t)(end - pos);
+            fast_tiles[p0.cls].push_back(t);
+            for (size_t q = pos; q < end; q++) {
+                const int64_t s = order[q];
+                dev_of[s] = dcur;
+                orig_of[dcur] = s;
+                nmap[dcur] = NodeMap{node_cursor, Lk, k, M, (int)(q - pos)};
+                dcur++;
+            }
+            node_cursor += (int64_t)M * Lk;
+            pos = end;
+        } else {
+            if (gen_tiles.empty()) b->gen_base = node_cursor;
+            size_t end = std::min(pos + (size_t)kWave, (size_t)S);
+            int n_max = 0;
+            for (size_t q = pos; q < end; q++) n_max = std::max(n_max, placed[order[q]].n);
+            GeneralTile t;
+            t.node_base = node_cursor;
+            t.surf_base = (int32_t)dcur;
+            t.G = (int32_t)(end - pos);
+            t.n_max = n_max;
+            t.pad = 0;
+            t.scratch_base = scratch_cursor;
+            gen_tiles.push_back(t);
+            for (size_t q = pos; q < end; q++) {
+                const int64_t s = order[q];
+                dev_of[s] = dcur;
+                orig_of[dcur] = s;
+                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos)};
+                dcur++;
+            }
+            node_cursor += (int64_t)n_max * kWave;
+            scratch_cursor += (int64_t)kScratchArrays * n_max * kWave;
+            pos = end;
+        }
+    }
+    if (gen_tiles.empty()) b->gen_base = node_cursor;
+    b->node_slots = node_cursor;
+    if (node_cursor >= (int64_t)1 << 32) return fail(HEAT_E_SIZE, "batch too large: %lld node slots", (long long)node_cursor);
+
+    auto node_index = [&](int64_t dsurf, int i) -> int64_t {
+        const NodeMap &m = nmap[dsurf];
+        if (m.M == 0) return m.base + (int64_t)i * kWave + m.g;
+        const int lane = m.g * m.k + i / m.M, j = i % m.M;
+        return m.base + ((int64_t)(j >> 1) * m.Lk + lane) * 2 + (j & 1);
+    };
+
+    // ---- per-node constants ----
+    std::vector<double> hV(node_cursor, 0.0), hU(node_cursor, 0.0);
+    const int64_t gen_slots = node_cursor - b->gen_base;
+    std::vector<double> hAf(gen_slots, 0.0), hAb(gen_slots, 0.0), hMass(gen_slots, 0.0);
+    std::vector<int32_t> hCav(gen_slots, -1);
+    for (int64_t dd = 0; dd < S; dd++) {
+        const int64_t s = orig_of[dd];
+        const int64_t o = d->node_offset[s];
+        const int n = placed[s].n;
+        const bool gen = placed[s].cls == 3;
+        for (int i = 0; i < n; i++) {
+            const int64_t idx = node_index(dd, i);
+            const double mass = d->mass[o + i];
+            hV[idx] = (mass >= kMassThreshold) ? d->dt / mass : 0.0;  // dt / C, surface.rs:172
+            const bool cav = d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0;
+            hU[idx] = cav ? 0.0 : d->uvalue[o + i];
+            if (gen) {
+                const int64_t gi = idx - b->gen_base;
+                hAf[gi] = d->front_alpha[o + i];
+                hAb[gi] = d->back_alpha[o + i];
+                hMass[gi] = mass;
+                hCav[gi] = cav ? d->seg_cavity[o + i] : -1;
+            }
+        }
+        node0_index[s] = node_index(dd, 0);
+        nodeN_index[s] = node_index(dd, n - 1);
+    }
+
+    // ---- per-surface constants (device order) ----
+    std::vector<int32_t> hMeta(S), hFz(S), hBz(S);
+    std::vector<double> hFamb(S), hBamb(S), hFe(S), hBe(S), hArea(S), hPer(S), hCos(S), hNx(S), hNy(S), hWm(S),
+        hAf0(S), hAbn(S), hFixF, hFixB;
+    std::vector<int64_t> hFirst(S), hSlots(8 * S);
+    const bool has_fix = d->front_hs_fix != nullptr;
+    if (has_fix) { hFixF.resize(S); hFixB.resize(S); }
+    for (int64_t dd = 0; dd < S; dd++) {
+        const int64_t s = orig_of[dd];
+        const int64_t o = d->node_offset[s];
+        const int n = placed[s].n;
+        hMeta[dd] = n | (d->front_kind[s] << 16) | (d->back_kind[s] << 18);
+        hFz[dd] = d->front_kind[s] == HEAT_BOUNDARY_SPACE ? d->front_zone[s] : 0;
+        hBz[dd] = d->back_kind[s] == HEAT_BOUNDARY_SPACE ? d->back_zone[s] : 0;
+        hFamb[dd] = d->front_ambient[s]; hBamb[dd] = d->back_ambient[s];
+        hFe[dd] = d->front_emissivity[s]; hBe[dd] = d->back_emissivity[s];
+        hArea[dd] = d->area[s]; hPer[dd] = d->perimeter[s];
+        hCos[dd] = d->cos_tilt[s]; hNx[dd] = d->normal_x[s]; hNy[dd] = d->normal_y[s];
+        hWm[dd] = d->wind_modifier[s];
+        hAf0[dd] = d->front_alpha[o];
+        hAbn[dd] = d->back_alpha[o + n - 1];
+        if (has_fix) { hFixF[dd] = d->front_hs_fix[s]; hFixB[dd] = d->back_hs_fix[s]; }
+        hFirst[dd] = d->first_node_slot[s];
+        const int64_t *src[8] = {d->hs_front_slot, d->hs_back_slot, d->flow_front_slot, d->flow_back_slot,
+                                 d->solar_front_slot, d->solar_back_slot, d->ir_front_slot, d->ir_back_slot};
+        for (int a = 0; a < 8; a++) hSlots[(int64_t)a * S + dd] = src[a][s];
+    }
+
+    // ---- zone contribution lists, in the reference's order (model.rs:562-585) ----
+    std::vector<int64_t> zoff(Z + 1, 0);
+    for (int64_t s = 0; s < S; s++) {
+        if (d->front_kind[s] == HEAT_BOUNDARY_SPACE) zoff[d->front_zone[s] + 1]++;
+        if (d->back_kind[s] == HEAT_BOUNDARY_SPACE) zoff[d->back_zone[s] + 1]++;
+    }
+    for (int64_t z = 0; z < Z; z++) zoff[z + 1] += zoff[z];
+    std::vector<ZoneEntry> zent(Z > 0 ? zoff[Z] : 0);
+    {
+        std::vector<int64_t> cur(zoff.begin(), zoff.end() - (Z >= 0 ? 1 : 0));
+        for (int64_t s = 0; s < S; s++) {
+            if (d->front_kind[s] == HEAT_BOUNDARY_SPACE) {
+                ZoneEntry e{(uint32_t)node0_index[s], (uint32_t)dev_of[s], d->area[s]};
+                zent[cur[d->front_zone[s]]++] = e;
+            }
+            if (d->back_kind[s] == HEAT_BOUNDARY_SPACE) {
+                ZoneEntry e{(uint32_t)nodeN_index[s], (uint32_t)(S + dev_of[s]), d->area[s]};
+                zent[cur[d->back_zone[s]]++] = e;
+            }
+        }
+    }
+
+    // ---- host copies used by download ----
+    b->h_first_slot.assign(d->first_node_slot, d->first_node_slot + S);
+    b->h_node_count.resize(S);
+    for (int64_t s = 0; s < S; s++) b->h_node_count[s] = placed[s].n;
+    b->h_out_slots[0].assign(d->hs_front_slot, d->hs_front_slot + S);
+    b->h_out_slots[1].assign(d->hs_back_slot, d->hs_back_slot + S);
+    b->h_out_slots[2].assign(d->flow_front_slot, d->flow_front_slot + S);
+    b->h_out_slots[3].assign(d->flow_back_slot, d->flow_back_slot + S);
+    if (Z > 0) b->h_zone_slot_h.assign(d->zone_slot, d->zone_slot + Z);
+
+    // ---- upload ----
+    for (int c = 0; c < 3; c++) {
+        b->n_fast_tiles[c] = (int)fast_tiles[c].size();
+        HIP_TRY(b->d_fast_tiles[c].upload(fast_tiles[c]));
+    }
+    b->n_gen_tiles = (int)gen_tiles.size();
+    HIP_TRY(b->d_gen_tiles.upload(gen_tiles));
+    HIP_TRY(b->d_T.zeros(node_cursor));
+    HIP_TRY(b->d_V.upload(hV));
+    HIP_TRY(b->d_U.upload(hU));
+    HIP_TRY(b->d_alpha_f.upload(hAf));
+    HIP_TRY(b->d_alpha_b.upload(hAb));
+    HIP_TRY(b->d_mass.upload(hMass));
+    HIP_TRY(b->d_cav_idx.upload(hCav));
+    HIP_TRY(b->d_scratch.alloc(scratch_cursor));
+    {
+        std::vector<CavityDev> hc(d->n_cavities);
+        for (int64_t c = 0; c < d->n_cavities; c++) {
+            const heat_cavity &x = d->cavities[c];
+            if (x.gas < 0 || x.gas > 3) return fail(HEAT_E_INVALID_ARG, "cavity %lld: unknown gas", (long long)c);
+            hc[c] = CavityDev{x.thickness, x.height, x.angle, x.eout, x.ein, x.gas, 0};
+        }
+        HIP_TRY(b->d_cavs.upload(hc));
+    }
+    HIP_TRY(b->d_meta.upload(hMeta));
+    HIP_TRY(b->d_front_zone.upload(hFz));
+    HIP_TRY(b->d_back_zone.upload(hBz));
+    HIP_TRY(b->d_front_amb.upload(hFamb));
+    HIP_TRY(b->d_back_amb.upload(hBamb));
+    HIP_TRY(b->d_front_emis.upload(hFe));
+    HIP_TRY(b->d_back_emis.upload(hBe));
+    HIP_TRY(b->d_area.upload(hArea));
+    HIP_TRY(b->d_perimeter.upload(hPer));
+    HIP_TRY(b->d_cos_tilt.upload(hCos));
+    HIP_TRY(b->d_nx.upload(hNx));
+    HIP_TRY(b->d_ny.upload(hNy));
+    HIP_TRY(b->d_wind_mod.upload(hWm));
+    HIP_TRY(b->d_alpha_f0.upload(hAf0));
+    HIP_TRY(b->d_alpha_bn.upload(hAbn));
+    if (has_fix) {
+        HIP_TRY(b->d_hs_fix_f.upload(hFixF));
+        HIP_TRY(b->d_hs_fix_b.upload(hFixB));
+    }
+    HIP_TRY(b->d_solar_f.zeros(S));
+    HIP_TRY(b->d_solar_b.zeros(S));
+    HIP_TRY(b->d_ir_f.zeros(S));
+    HIP_TRY(b->d_ir_b.zeros(S));
+    HIP_TRY(b->d_hs.zeros(2 * S));
+    HIP_TRY(b->d_flow.zeros(2 * S));
+    HIP_TRY(b->d_first_slot.upload(hFirst));
+    HIP_TRY(b->d_slots.upload(hSlots));
+    {
+        std::vector<int64_t> zs(Z);
+        std::vector<double> zv(Z);
+        for (int64_t z = 0; z < Z; z++) { zs[z] = d->zone_slot[z]; zv[z] = d->zone_volume[z]; }
+        HIP_TRY(b->d_zone_slot.upload(zs));
+        HIP_TRY(b->d_zone_vol.upload(zv));
+    }
+    HIP_TRY(b->d_zone_off.upload(zoff));
+    HIP_TRY(b->d_zone_entries.upload(zent));
+    HIP_TRY(b->d_zone_T.zeros(Z));
+    HIP_TRY(b->d_zone_a0.zeros(Z));
+    HIP_TRY(b->d_zone_b0.zeros(Z));
+    HIP_TRY(b->d_partial.zeros(2 * Z));
+    HIP_TRY(b->d_state.zeros(d->n_state));
+    HIP_TRY(b->d_step.zeros(1));
+    HIP_TRY(b->d_flags.zeros(1));
+    HIP_TRY(b->d_nomass_iters.zeros(1));
+    if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
+
+    // ---- argument bundles ----
+    SurfArrays &sa = b->sa;
+    sa.meta = b->d_meta.p; sa.front_zone = b->d_front_zone.p; sa.back_zone = b->d_back_zone.p;
+    sa.front_ambient = b->d_front_amb.p; sa.back_ambient = b->d_back_amb.p;
+    sa.front_emis = b->d_front_emis.p; sa.back_emis = b->d_back_emis.p;
+    sa.area = b->d_area.p; sa.perimeter = b->d_perimeter.p;
+    sa.cos_tilt = b->d_cos_tilt.p; sa.normal_x = b->d_nx.p; sa.normal_y = b->d_ny.p; sa.wind_mod = b->d_wind_mod.p;
+    sa.alpha_f0 = b->d_alpha_f0.p; sa.alpha_bn = b->d_alpha_bn.p;
+    sa.hs_fix_f = has_fix ? b->d_hs_fix_f.p : nullptr;
+    sa.hs_fix_b = has_fix ? b->d_hs_fix_b.p : nullptr;
+    sa.solar_f = b->d_solar_f.p; sa.solar_b = b->d_solar_b.p; sa.ir_f = b->d_ir_f.p; sa.ir_b = b->d_ir_b.p;
+    sa.hs_f = b->d_hs.p; sa.hs_b = b->d_hs.p + S;
+    sa.flow_f = b->d_flow.p; sa.flow_b = b->d_flow.p + S;
+    NodeArrays &na = b->na;
+    na.T = b->d_T.p; na.V = b->d_V.p; na.U = b->d_U.p;
+    na.alpha_f = b->d_alpha_f.p; na.alpha_b = b->d_alpha_b.p; na.cav = b->d_cav_idx.p; na.mass = b->d_mass.p;
+    SlotArrays &sl = b->sl;
+    const int64_t *sp = b->d_slots.p;
+    sl.hs_f = sp; sl.hs_b = sp + S; sl.flow_f = sp + 2 * S; sl.flow_b = sp + 3 * S;
+    sl.solar_f = sp + 4 * S; sl.solar_b = sp + 5 * S; sl.ir_f = sp + 6 * S; sl.ir_b = sp + 7 * S;
+    return HEAT_OK;
+}
+
+int select_device(heat_batch *b) {
+    HIP_TRY(hipSetDevice(b->device));
+    return HEAT_OK;
+}
+
+// iterate_surfaces for every group (model.rs:388-408)
+void enqueue_surfaces(heat_batch *b, int step_fixed) {
+    for (int c = 0; c < 3; c++)
+        launch_surfaces_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa, b->d_weather.p,
+                             b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p, b->stream);
+    launch_surfaces_general(b->d_gen_tiles.p, b->n_gen_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
+                            b->d_scratch.p, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
+                            b->d_nomass_iters.p, b->stream);
+}
+
+void enqueue_zones(heat_batch *b, int mode) {
+    launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_hs.p, b->d_zone_a0.p, b->d_zone_b0.p,
+                 b->d_zone_vol.p, b->d_zone_T.p, b->d_partial.p, (int)b->n_zones, b->dt, b->d_step.p,
+                 b->d_flags.p, mode, b->stream);
+}
+
+hipEvent_t next_event(heat_batch *b) {
+    if (b->ev_used == b->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        b->ev_pool.push_back(e);
+    }
+    return b->ev_pool[b->ev_used++];
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *heat_last_error(void) { return g_last_error.c_str(); }
+int heat_amd_abi_version(void) { return HEAT_AMD_ABI_VERSION; }
+
+int heat_batch_create(const heat_batch_desc *desc, heat_batch **out) {
+    heat_batch_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.device = -1;
+    opt.n_ranks = 1;
+    return heat_batch_create_ex(desc, &opt, out);
+}
+
+int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *opt_in, heat_batch **out) {
+    if (!out) return fail(HEAT_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    heat_batch_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.device = -1;
+    opt.n_ranks = 1;
+    if (opt_in) opt = *opt_in;
+    if (opt.n_ranks < 1) opt.n_ranks = 1;
+    if (opt.nodes_per_lane != 0 && opt.nodes_per_lane != 4 && opt.nodes_per_lane != 8 && opt.nodes_per_lane != 16)
+        return fail(HEAT_E_INVALID_ARG, "nodes_per_lane must be 0, 4, 8 or 16");
+    int rc = check_desc(desc);
+    if (rc) return rc;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(HEAT_E_DEVICE, "no HIP device available: this library has no CPU fallback");
+    heat_batch *b = new heat_batch();
+    if (opt.device >= 0) {
+        b->device = opt.device;
+    } else if (hipGetDevice(&b->device) != hipSuccess) {
+        delete b;
+        return fail(HEAT_E_DEVICE, "hipGetDevice failed");
+    }
+    b->n_ranks = opt.n_ranks;
+    b->rank = opt.rank;
+    b->use_graph = opt.use_graph != 0;
+    rc = select_device(b);
+    if (!rc) {
+        if (opt.stream) {
+            b->stream = reinterpret_cast<hipStream_t>(opt.stream);
+        } else {
+            hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) rc = fail(HEAT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
+            b->own_stream = true;
+        }
+    }
+    if (!rc) rc = build(b, desc, opt);
+    if (rc) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return HEAT_OK;
+}
+
+void heat_batch_destroy(heat_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    delete b;
+}
+
+int64_t heat_batch_n_surfaces(const heat_batch *b) { return b ? b->n_surf : 0; }
+int64_t heat_batch_n_nodes(const heat_batch *b) { return b ? b->n_nodes : 0; }
+int64_t heat_batch_n_zones(const heat_batch *b) { return b ? b->n_zones : 0; }
+int64_t heat_batch_algorithmic_bytes(const heat_batch *b) { return b ? b->algorithmic_bytes : 0; }
+int heat_batch_class_counts(const heat_batch *b, int64_t counts[4]) {
+    if (!b || !counts) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    for (int i = 0; i < 4; i++) counts[i] = b->class_counts[i];
+    return HEAT_OK;
+}
+
+static int transfer_in(heat_batch *b, const double *state, size_t n_state, bool full) {
+    if (!b || !state) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    if ((int64_t)n_state != b->n_state) return fail(HEAT_E_SIZE, "n_state %zu, batch was created for %lld", n_state, (long long)b->n_state);
+    int rc = select_device(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(b->d_state.p, state, n_state * sizeof(double), hipMemcpyHostToDevice));
+    if (full) {
+        for (int c = 0; c < 3; c++)
+            launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
+                              b->d_first_slot.p, b->d_state.p, 0, b->stream);
+        launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p,
+                             b->d_state.p, 0, b->stream);
+    }
+    launch_surf_scalars((int)b->n_surf, b->sl, b->sa, b->d_solar_f.p, b->d_solar_b.p, b->d_ir_f.p, b->d_ir_b.p,
+                        b->d_state.p, 0, full ? 3 : 1, b->stream);
+    launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 0, b->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return HEAT_OK;
+}
+
+int heat_batch_upload_state(heat_batch *b, const double *state, size_t n_state) {
+    return transfer_in(b, state, n_state, true);
+}
+int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state) {
+    return transfer_in(b, state, n_state, false);
+}
+
+int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
+    if (!b || !state) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    if ((int64_t)n_state != b->n_state) return fail(HEAT_E_SIZE, "n_state %zu, batch was created for %lld", n_state, (long long)b->n_state);
+    int rc = select_device(b);
+    if (rc) return rc;
+    for (int c = 0; c < 3; c++)
+        launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
+                          b->d_first_slot.p, b->d_state.p, 1, b->stream);
+    launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p, b->d_state.p,
+                         1, b->stream);
+    launch_surf_scalars((int)b->n_surf, b->sl, b->sa, b->d_solar_f.p, b->d_solar_b.p, b->d_ir_f.p, b->d_ir_b.p,
+                        b->d_state.p, 1, 2, b->stream);
+    launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 1, b->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    // Only the slots this path owns are written into the caller's array.
+    b->h_stage.resize(n_state);
+    HIP_TRY(hipMemcpy(b->h_stage.data(), b->d_state.p, n_state * sizeof(double), hipMemcpyDeviceToHost));
+    const double *src = b->h_stage.data();
+    for (int64_t s = 0; s < b->n_surf; s++) {
+        memcpy(state + b->h_first_slot[s], src + b->h_first_slot[s], (size_t)b->h_node_count[s] * sizeof(double));
+        for (int a = 0; a < 4; a++) state[b->h_out_slots[a][s]] = src[b->h_out_slots[a][s]];
+    }
+    for (int64_t z = 0; z < b->n_zones; z++) state[b->h_zone_slot_h[z]] = src[b->h_zone_slot_h[z]];
+    return HEAT_OK;
+}
+
+int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n_sub, const double *zone_a0,
+                           const double *zone_b0) {
+    if (!b || (!weather && n_sub > 0)) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    if (n_sub < 0) return fail(HEAT_E_INVALID_ARG, "n_sub < 0");
+    int rc = select_device(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));  // the pinned staging buffers are free again
+    if ((size_t)n_sub > b->weather_cap) {
+        if (b->h_weather) HIP_TRY(hipHostFree(b->h_weather));
+        b->h_weather = nullptr;
+        const size_t cap = std::max<size_t>((size_t)n_sub, 64);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_weather), cap * sizeof(StepWeather)));
+        HIP_TRY(b->d_weather.alloc(cap));
+        b->weather_cap = cap;
+        if (b->graph_exec) {  // the captured graph holds the old pointer
+            (void)hipGraphExecDestroy(b->graph_exec);
+            b->graph_exec = nullptr;
+        }
+    }
+    for (int i = 0; i < n_sub; i++) {
+        // sin/cos of the wind direction as is_windward takes them (surface.rs:40)
+        b->h_weather[i] = StepWeather{weather[i].dry_bulb, weather[i].wind_speed, std::sin(weather[i].wind_direction),
+                                      std::cos(weather[i].wind_direction)};
+    }
+    b->n_weather = n_sub;
+    if (n_sub > 0)
+        HIP_TRY(hipMemcpyAsync(b->d_weather.p, b->h_weather, (size_t)n_sub * sizeof(StepWeather),
+                               hipMemcpyHostToDevice, b->stream));
+    const int64_t Z = b->n_zones;
+    if (Z > 0) {
+        for (int64_t z = 0; z < Z; z++) {
+            b->h_zone_ab[z] = zone_a0 ? zone_a0[z] : 0.0;
+            b->h_zone_ab[Z + z] = zone_b0 ? zone_b0[z] : 0.0;
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_zone_a0.p, b->h_zone_ab, Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_zone_b0.p, b->h_zone_ab + Z, Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
+    launch_set_step(b->d_step.p, 0, b->stream);
+    HIP_TRY(hipGetLastError());
+    return HEAT_OK;
+}
+
+int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    if (sub_step < 0 || sub_step >= b->n_weather) return fail(HEAT_E_INVALID_ARG, "sub_step %d outside the weather set (%d)", sub_step, b->n_weather);
+    int rc = select_device(b);
+    if (rc) return rc;
+    enqueue_surfaces(b, sub_step);
+    enqueue_zones(b, 1);  // partial (a, b) of this rank's surfaces
+    HIP_TRY(hipGetLastError());
+    return HEAT_OK;
+}
+
+double *heat_batch_zone_partials(heat_batch *b) { return b ? b->d_partial.p : nullptr; }
+
+int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    if (n_blocks < 1) return fail(HEAT_E_INVALID_ARG, "n_blocks < 1");
+    int rc = select_device(b);
+    if (rc) return rc;
+    const double *g = gathered_dev ? gathered_dev : b->d_partial.p;
+    launch_zone_update(g, n_blocks, b->d_zone_a0.p, b->d_zone_b0.p, b->d_zone_vol.p, b->d_zone_T.p,
+                       (int)b->n_zones, b->dt, b->d_step.p, b->d_flags.p, b->stream);
+    HIP_TRY(hipGetLastError());
+    return HEAT_OK;
+}
+
+int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_t n_sub, const double *zone_a0,
+                              const double *zone_b0) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    if (b->n_ranks > 1)
+        return fail(HEAT_E_INVALID_ARG, "sharded batch: drive it with heat_batch_step_surfaces / heat_batch_step_zones");
+    int rc = heat_batch_set_weather(b, weather, n_sub, zone_a0, zone_b0);
+    if (rc) return rc;
+    if (b->timing) {
+        for (int i = 0; i < n_sub; i++) {
+            hipEvent_t e0 = next_event(b), e1 = next_event(b), e2 = next_event(b);
+            if (!e0 || !e1 || !e2) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e0, b->stream));
+            enqueue_surfaces(b, -1);
+            HIP_TRY(hipEventRecord(e1, b->stream));
+            enqueue_zones(b, 0);
+            HIP_TRY(hipEventRecord(e2, b->stream));
+        }
+    } else if (b->use_graph) {
+        if (!b->graph_exec) {
+            if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+            HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_surfaces(b, -1);
+            enqueue_zones(b, 0);
+            HIP_TRY(hipStreamEndCapture(b->stream, &b->graph));
+            HIP_TRY(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+        }
+        for (int i = 0; i < n_sub; i++) HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+    } else {
+        for (int i = 0; i < n_sub; i++) {
+            enqueue_surfaces(b, -1);
+            enqueue_zones(b, 0);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return HEAT_OK;
+}
+
+int heat_batch_synchronize(heat_batch *b) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    int rc = select_device(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    int f = 0;
+    HIP_TRY(hipMemcpy(&f, b->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    if (f) {
+        HIP_TRY(hipMemset(b->d_flags.p, 0, sizeof f));
+        return flags_to_status(f);
+    }
+    return HEAT_OK;
+}
+
+int heat_batch_march(heat_batch *b, double *state, size_t n_state, const heat_weather *weather, int32_t n_sub,
+                     const double *zone_a0, const double *zone_b0) {
+    int rc = heat_batch_upload_inputs(b, state, n_state);
+    if (rc) return rc;
+    rc = heat_batch_march_resident(b, weather, n_sub, zone_a0, zone_b0);
+    if (rc) return rc;
+    rc = heat_batch_synchronize(b);
+    if (rc) return rc;
+    return heat_batch_download_state(b, state, n_state);
+}
+
+int64_t heat_batch_nomass_iterations(heat_batch *b) {
+    if (!b) return 0;
+    if (hipSetDevice(b->device) != hipSuccess) return -1;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return -1;
+    unsigned long long v = 0;
+    if (hipMemcpy(&v, b->d_nomass_iters.p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
+int heat_batch_set_timing(heat_batch *b, int32_t enabled) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    b->timing = enabled != 0;
+    b->ev_used = 0;
+    return HEAT_OK;
+}
+
+int heat_batch_get_timing(heat_batch *b, double *surf_us, double *substep_us, int64_t *n_samples) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    int rc = select_device(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    double s_surf = 0, s_all = 0;
+    const size_t n = b->ev_used / 3;
+    for (size_t i = 0; i < n; i++) {
+        float ms1 = 0, ms2 = 0;
+        HIP_TRY(hipEventElapsedTime(&ms1, b->ev_pool[3 * i], b->ev_pool[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms2, b->ev_pool[3 * i], b->ev_pool[3 * i + 2]));
+        s_surf += ms1;
+        s_all += ms2;
+    }
+    if (surf_us) *surf_us = n ? s_surf * 1000.0 / (double)n : 0.0;
+    if (substep_us) *substep_us = n ? s_all * 1000.0 / (double)n : 0.0;
+    if (n_samples) *n_samples = (int64_t)n;
+    b->ev_used = 0;
+    return HEAT_OK;
+}
+
+}  // extern "C"

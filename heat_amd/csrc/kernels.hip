@@ -1,0 +1,716 @@
+// kernels.hip — gfx950 kernels of the wall heat-conduction path.
+//
+//   k_surfaces_fast<M>   iterate_surfaces (reference src/model.rs:102-180) for all-massive,
+//                        solid-conductance, opaque surfaces: lane-blocked RK4 stencil in registers,
+//                        M nodes per lane, neighbour exchange by wave shuffles.
+//   k_surfaces_general   the same reference function for ANY surface (no-mass chunks, gas
+//                        cavities, per-node solar absorption): one lane per surface, tri-diagonal
+//                        matrices in a global scratch area, operation order of the reference.
+//   k_zones              calculate_zones_abc + estimate_zones_future_temperatures
+//                        (src/model.rs:489-597,650-674): one wavefront per zone.
+//   k_zone_update        the zone update from gathered per-rank partial sums (multi-GPU).
+//   k_gather_* / k_scatter_*   SurfaceTrait slot accessors (src/surface_trait.rs:81-164) in bulk.
+//
+// No MFMA anywhere: this is an HBM-bound f64 stencil.
+#include <hip/hip_runtime.h>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+#include "layout.hpp"
+
+namespace heat {
+
+// ---------------------------------------------------------------------------
+// Boundary conditions of one side — reference src/surface.rs:596-717.
+//   kind      Boundary kind of this side
+//   air_t     boundary temperature of this side (get_boundary_temperature, model.rs:79-96)
+//   rad_alt   rad_temperature for non-Outdoor kinds (t_front / t_back / quirk, surface.rs:616,631,665,676)
+//   surf_t    surface temperature the reference reads from `state` for this side
+//   cos_eff   cos_surface_tilt as the reference sets it (front Outdoor flips the sign, surface.rs:652)
+__device__ __forceinline__ void eval_side(int kind, double air_t, double rad_alt, double ir, double surf_t,
+                                          double cos_eff, double air_speed, double area, double perimeter,
+                                          bool windward, bool need_rad, double &hs, double &rad_t, int &bad) {
+    const double natural = tarp_natural(air_t, surf_t, cos_eff, bad);
+    if (kind == KIND_OUTDOOR) {
+        hs = tarp_forced(air_speed, area, perimeter, windward) + natural;
+        rad_t = need_rad ? ir_to_rad_temperature(ir) : 0.0;
+    } else {
+        hs = natural;
+        rad_t = rad_alt;
+    }
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
+
+// ---------------------------------------------------------------------------
+// Fast path. One wavefront per tile; see layout.hpp for the lane blocking.
+template <int M>
+__global__ void __launch_bounds__(256)
+k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SurfArrays sa,
+                const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                const double *__restrict__ zone_T, int *__restrict__ flags) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+
+    const FastTile tile = tiles[wave];
+    const int k = tile.k;
+    const int G = tile.G;
+    const int Lk = (kWave / k) * k;
+    int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
+    const int seg = lane - g * k;
+    const bool in_layout = lane < Lk;
+    const bool active = in_layout && (g < G);
+    if (!active) g = 0;
+    const int d = tile.surf_base + g;
+    const int ll = in_layout ? lane : 0;
+
+    // ---- node data: T, V = dt/C, U (coalesced 16-byte loads) ----
+    double T[M], V[M], U[M];
+    {
+        const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
+        const double2 *pV = reinterpret_cast<const double2 *>(na.V + tile.node_base);
+        const double2 *pU = reinterpret_cast<const double2 *>(na.U + tile.node_base);
+#pragma unroll
+        for (int jp = 0; jp < M / 2; jp++) {
+            const double2 t = pT[jp * Lk + ll];
+            const double2 v = pV[jp * Lk + ll];
+            const double2 u = pU[jp * Lk + ll];
+            T[2 * jp] = t.x; T[2 * jp + 1] = t.y;
+            V[2 * jp] = v.x; V[2 * jp + 1] = v.y;
+            U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
+        }
+    }
+
+    // ---- per-surface scalars (every lane of a surface reads the same address) ----
+    const int meta = sa.meta[d];
+    const int nn = meta & 0xffff;
+    const int fk = (meta >> 16) & 3;
+    const int bk = (meta >> 18) & 3;
+    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const StepWeather w = weather[step];
+    const double cos_tilt = sa.cos_tilt[d];
+    const double area = sa.area[d];
+    const double perimeter = sa.perimeter[d];
+    const double air_speed = w.wind_speed * sa.wind_mod[d];
+    const bool windward = is_windward(w.sin_wd, w.cos_wd, cos_tilt, sa.normal_x[d], sa.normal_y[d]);
+
+    double t_front_b, t_back_b;  // get_boundary_temperature, model.rs:79-96
+    if (fk == KIND_SPACE) t_front_b = zone_T[sa.front_zone[d]];
+    else if (fk == KIND_AMBIENT) t_front_b = sa.front_ambient[d];
+    else t_front_b = w.t_out;
+    if (bk == KIND_SPACE) t_back_b = zone_T[sa.back_zone[d]];
+    else if (bk == KIND_AMBIENT) t_back_b = sa.back_ambient[d];
+    else t_back_b = w.t_out;
+
+    const bool is_first = (seg == 0);
+    const bool is_last = (seg == k - 1);
+    const int jl = nn - 1 - (k - 1) * M;  // local index of the last node inside the last lane
+    const int first_lane = g * k;
+    const int last_lane = min(g * k + k - 1, kWave - 1);
+
+    auto pick_last = [&](const double (&x)[M]) {
+        double r = x[0];
+#pragma unroll
+        for (int j = 1; j < M; j++) r = (j == jl) ? x[j] : r;
+        return r;
+    };
+
+    // Surface temperatures as the reference reads them from `state` (pre-step).
+    const double T0 = shfl_f64(T[0], first_lane);
+    const double Tn = shfl_f64(pick_last(T), last_lane);
+
+    int bad = 0;
+    // Which side this lane evaluates: the first lane the front, every other lane the back
+    // (only the last lane's value is used). Tiles with k == 1 evaluate both, one after the other.
+    auto side = [&](bool back, double T0v, double Tnv, bool need_rad, double &hs, double &rad_t) {
+        const int kind = back ? bk : fk;
+        const double air_t = back ? t_back_b : t_front_b;
+        // back/Ambient uses t_front and the FRONT temperature (surface.rs:672-686)
+        const bool quirk = back && (bk == KIND_AMBIENT);
+        const double rad_alt = (back && !quirk) ? t_back_b : t_front_b;
+        const double surf_t = (back && !quirk) ? Tnv : T0v;
+        const double cos_eff = (!back && fk == KIND_OUTDOOR) ? -cos_tilt : cos_tilt;
+        const double ir = need_rad ? (back ? sa.ir_b[d] : sa.ir_f[d]) : 0.0;
+        eval_side(kind, air_t, rad_alt, ir, surf_t, cos_eff, air_speed, area, perimeter, windward, need_rad,
+                  hs, rad_t, bad);
+        if (hs != hs) bad |= FLAG_NAN_HS;  // surface.rs:704-707
+        if (sa.hs_fix_f != nullptr) {      // debug overrides, surface.rs:708-714
+            const double fix = back ? sa.hs_fix_b[d] : sa.hs_fix_f[d];
+            if (fix == fix) hs = fix;
+        }
+        return surf_t;
+    };
+
+    // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769),
+    // already multiplied by V = dt/C as rearrange_k does (surface.rs:168-187).
+    double GV[M], QP[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) { GV[j] = 0.0; QP[j] = 0.0; }
+
+    auto add_front = [&](double hs, double rad_t, double surf_t) {
+        const double rhs = rad_hs(sa.front_emis[d], rad_t, surf_t);
+        double sol = sa.solar_f[d];
+        if (sol != sol || sol < 0.0) sol = 0.0;
+        const double q = (t_front_b * hs + rhs * (rad_t - T[0])) + sa.alpha_f0[d] * sol;
+        GV[0] += V[0] * hs;
+        QP[0] += V[0] * q;
+    };
+    auto add_back = [&](double hs, double rad_t, double surf_t) {
+        const double rhs = rad_hs(sa.back_emis[d], rad_t, surf_t);
+        double sol = sa.solar_b[d];
+        if (sol != sol) sol = 0.0;  // sic: only NaN is clamped (surface.rs:920-923)
+        const double tl = pick_last(T);
+        const double q = (t_back_b * hs + rhs * (rad_t - tl)) + sa.alpha_bn[d] * sol;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            if (j == jl) {
+                GV[j] += V[j] * hs;
+                QP[j] += V[j] * q;
+            }
+        }
+    };
+
+    if (k == 1) {
+        double hs, rad_t, surf_t;
+        surf_t = side(false, T0, Tn, true, hs, rad_t);
+        add_front(hs, rad_t, surf_t);
+        surf_t = side(true, T0, Tn, true, hs, rad_t);
+        add_back(hs, rad_t, surf_t);
+    } else {
+        double hs, rad_t;
+        const double surf_t = side(!is_first, T0, Tn, true, hs, rad_t);
+        if (is_first) add_front(hs, rad_t, surf_t);
+        if (is_last) add_back(hs, rad_t, surf_t);
+    }
+
+    // ---- RK4 on dT/dt = V (flux_right - flux_left - g T) + qp  (surface.rs:228-308) ----
+    // Conductance towards the previous lane's last node.
+    double UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
+    if (is_first) UL = 0.0;
+
+    auto rhs_eval = [&](const double (&x)[M], double (&kk)[M]) {
+        double xl = shfl_f64(x[M - 1], (lane + kWave - 1) & (kWave - 1));
+        double xr = shfl_f64(x[0], (lane + 1) & (kWave - 1));
+        if (is_first) xl = 0.0;  // never let another surface's value (possibly NaN) in
+        if (is_last) xr = 0.0;
+        double fprev = UL * (x[0] - xl);
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            const double xn = (j == M - 1) ? xr : x[(j + 1) % M];
+            const double f = U[j] * (xn - x[j]);
+            kk[j] = V[j] * (f - fprev) - GV[j] * x[j] + QP[j];
+            fprev = f;
+        }
+    };
+
+    double acc[M], aux[M], kk[M];
+    rhs_eval(T, kk);
+#pragma unroll
+    for (int j = 0; j < M; j++) { acc[j] = T[j] + kk[j] * (1.0 / 6.0); aux[j] = T[j] + 0.5 * kk[j]; }
+    rhs_eval(aux, kk);
+#pragma unroll
+    for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + 0.5 * kk[j]; }
+    rhs_eval(aux, kk);
+#pragma unroll
+    for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + kk[j]; }
+    rhs_eval(aux, kk);
+#pragma unroll
+    for (int j = 0; j < M; j++) T[j] = acc[j] + kk[j] * (1.0 / 6.0);
+
+    // ---- write back node temperatures (model.rs:145-147) ----
+    if (active) {
+        double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
+#pragma unroll
+        for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(T[2 * jp], T[2 * jp + 1]);
+    }
+
+    // ---- convection coefficients with the NEW temperatures + heat flows (model.rs:150-169) ----
+    const double T0n = shfl_f64(T[0], first_lane);
+    const double Tln = pick_last(T);
+    const double Tnn = shfl_f64(Tln, last_lane);
+    if (k == 1) {
+        double hs, rad_t;
+        side(false, T0n, Tnn, false, hs, rad_t);
+        if (active) { sa.hs_f[d] = hs; sa.flow_f[d] = (T[0] - t_front_b) * hs; }
+        side(true, T0n, Tnn, false, hs, rad_t);
+        if (active) { sa.hs_b[d] = hs; sa.flow_b[d] = (Tln - t_back_b) * hs; }
+    } else {
+        double hs, rad_t;
+        side(!is_first, T0n, Tnn, false, hs, rad_t);
+        if (active && is_first) { sa.hs_f[d] = hs; sa.flow_f[d] = (T[0] - t_front_b) * hs; }
+        if (active && is_last) { sa.hs_b[d] = hs; sa.flow_b[d] = (Tln - t_back_b) * hs; }
+        if (!(is_first || is_last)) bad = 0;
+    }
+    if (active && bad) atomicOr(flags, bad);
+}
+
+// ---------------------------------------------------------------------------
+// General path: one lane per surface, reference operation order, no FMA contraction.
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256)
+k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
+                   SurfArrays sa, const CavityDev *__restrict__ cavs, double *__restrict__ scratch,
+                   const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                   const double *__restrict__ zone_T, int *__restrict__ flags,
+                   unsigned long long *__restrict__ nomass_iters) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+    const GeneralTile tile = tiles[wave];
+    if (lane >= tile.G) return;
+    const int d = tile.surf_base + lane;
+
+    const int meta = sa.meta[d];
+    const int nn = meta & 0xffff;
+    const int fk = (meta >> 16) & 3;
+    const int bk = (meta >> 18) & 3;
+    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const StepWeather w = weather[step];
+
+    double *Tg = na.T + tile.node_base + lane;                       // T(i) = Tg[i*64]
+    const double *Vg = na.V + tile.node_base + lane;
+    const double *Ug = na.U + tile.node_base + lane;
+    const int64_t gofs = tile.node_base - gen_base + lane;
+    const double *Fa = na.alpha_f + gofs;
+    const double *Ba = na.alpha_b + gofs;
+    const double *Mg = na.mass + gofs;
+    const int32_t *Cg = na.cav + gofs;
+    const int nmax = tile.n_max;
+    double *S = scratch + tile.scratch_base + lane;                  // S(a, i) = S[(a*nmax + i)*64]
+#define SC(a, i) S[((int64_t)(a) * nmax + (i)) * kWave]
+#define TT(i) Tg[(int64_t)(i) * kWave]
+    enum { LO = 0, DG = 1, UP = 2, QQ = 3, AUX = 4, KN = 5, ACC = 6 };
+
+    int bad = 0;
+    const double cos_tilt = sa.cos_tilt[d];
+    const double area = sa.area[d];
+    const double perimeter = sa.perimeter[d];
+    const double air_speed = w.wind_speed * sa.wind_mod[d];
+    const bool windward = is_windward(w.sin_wd, w.cos_wd, cos_tilt, sa.normal_x[d], sa.normal_y[d]);
+
+    double t_front_b, t_back_b;
+    if (fk == KIND_SPACE) t_front_b = zone_T[sa.front_zone[d]];
+    else if (fk == KIND_AMBIENT) t_front_b = sa.front_ambient[d];
+    else t_front_b = w.t_out;
+    if (bk == KIND_SPACE) t_back_b = zone_T[sa.back_zone[d]];
+    else if (bk == KIND_AMBIENT) t_back_b = sa.back_ambient[d];
+    else t_back_b = w.t_out;
+
+    // calc_border_conditions on the pre-step state (surface.rs:596-717): identical for every
+    // call made before the write-back at model.rs:145-147.
+    const double T0 = TT(0), Tn = TT(nn - 1);
+    const bool quirk = (bk == KIND_AMBIENT);
+    double f_hs, f_rad, b_hs, b_rad;
+    const double f_surf = T0;
+    const double b_surf = quirk ? T0 : Tn;
+    eval_side(fk, t_front_b, t_front_b, sa.ir_f[d], f_surf, (fk == KIND_OUTDOOR) ? -cos_tilt : cos_tilt,
+              air_speed, area, perimeter, windward, true, f_hs, f_rad, bad);
+    eval_side(bk, t_back_b, quirk ? t_front_b : t_back_b, sa.ir_b[d], b_surf, cos_tilt,
+              air_speed, area, perimeter, windward, true, b_hs, b_rad, bad);
+    if (f_hs != f_hs || b_hs != b_hs) bad |= FLAG_NAN_HS;
+    if (sa.hs_fix_f != nullptr) {
+        const double ff = sa.hs_fix_f[d], fb = sa.hs_fix_b[d];
+        if (ff == ff) f_hs = ff;
+        if (fb == fb) b_hs = fb;
+    }
+    const double f_air = t_front_b, b_air = t_back_b;
+    const double f_radhs = rad_hs(sa.front_emis[d], f_rad, f_surf);  // surface.rs:941-948
+    const double b_radhs = rad_hs(sa.back_emis[d], b_rad, b_surf);
+
+    double solar_front = sa.solar_f[d];
+    if (solar_front != solar_front || solar_front < 0.0) solar_front = 0.0;  // surface.rs:916-919
+    double solar_back = sa.solar_b[d];
+    if (solar_back != solar_back) solar_back = 0.0;                          // surface.rs:920-923 (sic)
+    auto solar = [&](int i) {  // surface.rs:930-931
+        double s = Fa[(int64_t)i * kWave] * solar_front;
+        s += Ba[(int64_t)i * kWave] * solar_back;
+        return s;
+    };
+    auto uval = [&](int gidx, double ta, double tb) {  // UValue::u_value, discretization.rs:48-55
+        const int c = Cg[(int64_t)gidx * kWave];
+        if (c >= 0) return cavity_u_value(cavs[c], ta, tb, bad);
+        return Ug[(int64_t)gidx * kWave];
+    };
+    // Discretization::get_k_q (discretization.rs:596-700) into LO/DG/UP/QQ
+    auto get_k_q = [&](int ini, int fin) {
+        const int nc = fin - ini;
+        for (int li = 0; li < nc; li++) { SC(LO, li) = 0.0; SC(DG, li) = 0.0; SC(UP, li) = 0.0; SC(QQ, li) = 0.0; }
+        for (int li = 0; li < nc - 1; li++) {
+            const int gi = ini + li;
+            const double u = uval(gi, TT(gi), TT(gi + 1));
+            SC(DG, li) += -u;
+            SC(DG, li + 1) = SC(DG, li + 1) - u;
+            SC(UP, li) = SC(UP, li) + u;
+            SC(LO, li + 1) = SC(LO, li + 1) + u;
+        }
+        double hf, fq;
+        if (ini == 0) {
+            const double ts = TT(0);
+            fq = f_air * f_hs + f_radhs * (f_rad - ts);
+            hf = f_hs;
+        } else {
+            const double tb = TT(ini - 1), ta = TT(ini);
+            const double u = uval(ini - 1, tb, ta);
+            hf = u;
+            fq = u * tb;
+        }
+        SC(QQ, 0) += fq;
+        SC(DG, 0) += -hf;
+        double hb, bq;
+        if (fin == nn) {
+            const double ts = TT(fin - 1);
+            bq = b_air * b_hs + b_radhs * (b_rad - ts);
+            hb = b_hs;
+        } else {
+            const double tb = TT(fin - 1), ta = TT(fin);
+            const double u = uval(fin - 1, tb, ta);
+            hb = u;
+            bq = u * ta;
+        }
+        SC(QQ, nc - 1) += bq;
+        SC(DG, nc - 1) += -hb;
+    };
+    auto matvec = [&](int li, int nc, auto xfn) {  // Matrix::prod_tri_diag_into, one row
+        double a = 0.0;
+        if (li > 0) a += SC(LO, li) * xfn(li - 1);
+        a += SC(DG, li) * xfn(li);
+        if (li < nc - 1) a += SC(UP, li) * xfn(li + 1);
+        return a;
+    };
+
+    // ---- no-mass chunks first (surface.rs:950-965, march_nomass :790-898) ----
+    unsigned long long iters = 0;
+    for (int i = 0; i < nn;) {
+        if (Mg[(int64_t)i * kWave] >= kMassThreshold) { i++; continue; }
+        const int ini = i;
+        while (i < nn && Mg[(int64_t)i * kWave] < kMassThreshold) i++;
+        const int fin = i, nc = fin - ini;
+        double old_err = 99999.;
+        int count = 0;
+        for (;;) {
+            get_k_q(ini, fin);
+            iters++;
+            for (int li = 0; li < nc; li++) SC(QQ, li) = (SC(QQ, li) + solar(ini + li)) * -1.;
+            // mut_n_diag_gaussian(q, 3): elimination + back-substitution; x overwrites QQ
+            for (int li = 1; li < nc; li++) {
+                const double f = SC(LO, li) / SC(DG, li - 1);
+                SC(DG, li) -= f * SC(UP, li - 1);
+                SC(QQ, li) -= f * SC(QQ, li - 1);
+            }
+            SC(QQ, nc - 1) = SC(QQ, nc - 1) / SC(DG, nc - 1);
+            for (int li = nc - 2; li >= 0; li--) SC(QQ, li) = (SC(QQ, li) - SC(UP, li) * SC(QQ, li + 1)) / SC(DG, li);
+            double err = 0.0;
+            for (int li = 0; li < nc; li++) err += fabs(SC(QQ, li) - TT(ini + li));
+            if (err > old_err) break;                         // surface.rs:842-848
+            if (err != err) { bad |= FLAG_NAN_NOMASS; break; }  // surface.rs:850
+            for (int li = 0; li < nc; li++) TT(ini + li) = (TT(ini + li) + SC(QQ, li)) * 0.5;
+            const double tol = (count < 100) ? 0.01 : 0.5;  // surface.rs:885
+            if (err / (double)nc < tol) break;
+            old_err = err;
+            count++;
+        }
+    }
+
+    // ---- massive chunks (surface.rs:984-1000, march_mass :720-787, rk4 :228-308) ----
+    for (int i = 0; i < nn;) {
+        if (Mg[(int64_t)i * kWave] < kMassThreshold) { i++; continue; }
+        const int ini = i;
+        while (i < nn && Mg[(int64_t)i * kWave] >= kMassThreshold) i++;
+        const int fin = i, nc = fin - ini;
+        get_k_q(ini, fin);
+        for (int li = 0; li < nc; li++) {
+            const double v = Vg[(int64_t)(ini + li) * kWave];  // dt / C (host-computed, same IEEE division)
+            SC(QQ, li) = (SC(QQ, li) + solar(ini + li)) * v;
+            if (li > 0) SC(LO, li) *= v;
+            SC(DG, li) *= v;
+            if (li < nc - 1) SC(UP, li) *= v;
+        }
+        auto xT = [&](int li) { return TT(ini + li); };
+        auto xA = [&](int li) { return SC(AUX, li); };
+        for (int li = 0; li < nc; li++) SC(KN, li) = matvec(li, nc, xT) + SC(QQ, li);
+        for (int li = 0; li < nc; li++) {
+            const double k1 = SC(KN, li), t = TT(ini + li);
+            SC(AUX, li) = k1 * 0.5 + t;
+            SC(ACC, li) = t + k1 / 6.;
+        }
+        for (int li = 0; li < nc; li++) SC(KN, li) = matvec(li, nc, xA) + SC(QQ, li);
+        for (int li = 0; li < nc; li++) {
+            const double k2 = SC(KN, li), t = TT(ini + li);
+            SC(AUX, li) = k2 * 0.5 + t;
+            SC(ACC, li) += k2 / 3.;
+        }
+        for (int li = 0; li < nc; li++) SC(KN, li) = matvec(li, nc, xA) + SC(QQ, li);
+        for (int li = 0; li < nc; li++) {
+            const double k3 = SC(KN, li), t = TT(ini + li);
+            SC(AUX, li) = k3 + t;
+            SC(ACC, li) += k3 / 3.;
+        }
+        for (int li = 0; li < nc; li++) SC(KN, li) = matvec(li, nc, xA) + SC(QQ, li);
+        for (int li = 0; li < nc; li++) TT(ini + li) = SC(ACC, li) + SC(KN, li) / 6.;
+    }
+
+    // ---- outputs (model.rs:150-169): coefficients with the new surface temperatures ----
+    {
+        const double T0n = TT(0), Tnn = TT(nn - 1);
+        double fh, bh, r_;
+        eval_side(fk, t_front_b, t_front_b, 0.0, T0n, (fk == KIND_OUTDOOR) ? -cos_tilt : cos_tilt,
+                  air_speed, area, perimeter, windward, false, fh, r_, bad);
+        eval_side(bk, t_back_b, 0.0, 0.0, quirk ? T0n : Tnn, cos_tilt,
+                  air_speed, area, perimeter, windward, false, bh, r_, bad);
+        if (fh != fh || bh != bh) bad |= FLAG_NAN_HS;
+        if (sa.hs_fix_f != nullptr) {
+            const double ff = sa.hs_fix_f[d], fb = sa.hs_fix_b[d];
+            if (ff == ff) fh = ff;
+            if (fb == fb) bh = fb;
+        }
+        sa.hs_f[d] = fh;
+        sa.hs_b[d] = bh;
+        sa.flow_f[d] = (T0n - t_front_b) * fh;
+        sa.flow_b[d] = (Tnn - t_back_b) * bh;
+    }
+    if (bad) atomicOr(flags, bad);
+    if (iters) atomicAdd(nomass_iters, iters);
+#undef SC
+#undef TT
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// Zones: one wavefront per zone. mode 0: full update; mode 1: write partial (a, b) only.
+__global__ void __launch_bounds__(256)
+k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entries,
+        const double *__restrict__ T, const double *__restrict__ hs,
+        const double *__restrict__ a0, const double *__restrict__ b0, const double *__restrict__ zone_vol,
+        double *__restrict__ zone_T, double *__restrict__ partial, int n_zones, double dt,
+        int *__restrict__ step_ptr, int *__restrict__ flags, int mode) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int z = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mode == 0) *step_ptr += 1;
+    if (z >= n_zones) return;
+    double a = 0.0, b = 0.0;
+    const int64_t e0 = zone_off[z], e1 = zone_off[z + 1];
+    for (int64_t e = e0 + lane; e < e1; e += kWave) {  // model.rs:562-585
+        const ZoneEntry en = entries[e];
+        const double h = hs[en.hs_index];
+        const double ha = h * en.area;
+        a += ha * T[en.t_index];
+        b += ha;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {  // fixed tree: run-to-run deterministic
+        a += __shfl_down(a, o, kWave);
+        b += __shfl_down(b, o, kWave);
+    }
+    if (lane != 0) return;
+    if (mode == 1) {
+        partial[z] = a;
+        partial[n_zones + z] = b;
+        return;
+    }
+    a += a0[z];
+    b += b0[z];
+    const double tc = zone_T[z];
+    const double c = zone_mcp(zone_vol[z], tc);  // model.rs:549-552
+    double ft = tc;
+    if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);  // model.rs:662-666
+    if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);                      // model.rs:417-420
+    zone_T[z] = ft;
+}
+
+// Zone update from n_blocks gathered partial blocks ([block][2][n_zones]), summed in block order.
+__global__ void __launch_bounds__(256)
+k_zone_update(const double *__restrict__ gathered, int n_blocks, const double *__restrict__ a0,
+              const double *__restrict__ b0, const double *__restrict__ zone_vol,
+              double *__restrict__ zone_T, int n_zones, double dt, int *__restrict__ step_ptr,
+              int *__restrict__ flags) {
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z == 0) *step_ptr += 1;
+    if (z >= n_zones) return;
+    double a = a0[z], b = b0[z];
+    for (int r = 0; r < n_blocks; r++) {
+        a += gathered[(int64_t)r * 2 * n_zones + z];
+        b += gathered[(int64_t)r * 2 * n_zones + n_zones + z];
+    }
+    const double tc = zone_T[z];
+    const double c = zone_mcp(zone_vol[z], tc);
+    double ft = tc;
+    if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);
+    if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);
+    zone_T[z] = ft;
+}
+
+// ---------------------------------------------------------------------------
+// State transfer between the caller's flat SimulationState mirror and the device layout.
+template <int M>
+__global__ void __launch_bounds__(256)
+k_nodes_fast(const FastTile *__restrict__ tiles, int n_tiles, double *__restrict__ Tbuf,
+             const int32_t *__restrict__ meta, const int64_t *__restrict__ first_slot,
+             double *__restrict__ state, int to_state) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+    const FastTile tile = tiles[wave];
+    const int k = tile.k;
+    const int Lk = (kWave / k) * k;
+    const int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
+    const int seg = lane - g * k;
+    if (lane >= Lk) return;
+    const bool active = g < tile.G;
+    const int d = tile.surf_base + (active ? g : 0);
+    const int nn = active ? (meta[d] & 0xffff) : 0;
+    const int64_t slot0 = first_slot[d];
+    double *p = Tbuf + tile.node_base;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const int i = seg * M + j;
+        const int64_t idx = ((int64_t)(j >> 1) * Lk + lane) * 2 + (j & 1);
+        if (to_state) {
+            if (i < nn) state[slot0 + i] = p[idx];
+        } else {
+            p[idx] = (i < nn) ? state[slot0 + i] : 0.0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_nodes_general(const GeneralTile *__restrict__ tiles, int n_tiles, double *__restrict__ Tbuf,
+                const int32_t *__restrict__ meta, const int64_t *__restrict__ first_slot,
+                double *__restrict__ state, int to_state) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+    const GeneralTile tile = tiles[wave];
+    const bool active = lane < tile.G;
+    const int d = tile.surf_base + (active ? lane : 0);
+    const int nn = active ? (meta[d] & 0xffff) : 0;
+    const int64_t slot0 = first_slot[d];
+    double *p = Tbuf + tile.node_base + lane;
+    for (int i = 0; i < tile.n_max; i++) {
+        if (to_state) {
+            if (i < nn) state[slot0 + i] = p[(int64_t)i * kWave];
+        } else {
+            p[(int64_t)i * kWave] = (i < nn) ? state[slot0 + i] : 0.0;
+        }
+    }
+}
+
+// what: bit 0 inputs (solar, ir), bit 1 outputs (hs, flow)
+__global__ void __launch_bounds__(256)
+k_surf_scalars(int n_surf, SlotArrays sl, SurfArrays sa, double *__restrict__ solar_f, double *__restrict__ solar_b,
+               double *__restrict__ ir_f, double *__restrict__ ir_b, double *__restrict__ state, int to_state,
+               int what) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_surf) return;
+    if (to_state) {
+        if (what & 2) {
+            state[sl.hs_f[d]] = sa.hs_f[d];
+            state[sl.hs_b[d]] = sa.hs_b[d];
+            state[sl.flow_f[d]] = sa.flow_f[d];
+            state[sl.flow_b[d]] = sa.flow_b[d];
+        }
+    } else {
+        if (what & 1) {
+            solar_f[d] = state[sl.solar_f[d]];
+            solar_b[d] = state[sl.solar_b[d]];
+            ir_f[d] = state[sl.ir_f[d]];
+            ir_b[d] = state[sl.ir_b[d]];
+        }
+        if (what & 2) {
+            sa.hs_f[d] = state[sl.hs_f[d]];
+            sa.hs_b[d] = state[sl.hs_b[d]];
+            sa.flow_f[d] = state[sl.flow_f[d]];
+            sa.flow_b[d] = state[sl.flow_b[d]];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_zone_scalars(int n_zones, const int64_t *__restrict__ zone_slot, double *__restrict__ zone_T,
+               double *__restrict__ state, int to_state) {
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= n_zones) return;
+    if (to_state) state[zone_slot[z]] = zone_T[z];
+    else zone_T[z] = state[zone_slot[z]];
+}
+
+__global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
+
+// ---------------------------------------------------------------------------
+// Launch wrappers (host).
+static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
+
+void launch_surfaces_fast(int M, const FastTile *tiles, int n_tiles, const NodeArrays &na, const SurfArrays &sa,
+                          const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
+                          int *flags, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    const dim3 grid(blocks_for_waves(n_tiles)), block(256);
+    switch (M) {
+    case 4: hipLaunchKernelGGL(k_surfaces_fast<4>, grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, step_fixed, zone_T, flags); break;
+    case 8: hipLaunchKernelGGL(k_surfaces_fast<8>, grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, step_fixed, zone_T, flags); break;
+    default: hipLaunchKernelGGL(k_surfaces_fast<16>, grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, step_fixed, zone_T, flags); break;
+    }
+}
+
+void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
+                             const SurfArrays &sa, const CavityDev *cavs, double *scratch,
+                             const StepWeather *weather, const int *step_ptr, int step_fixed,
+                             const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_surfaces_general, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, na,
+                       gen_base, sa, cavs, scratch, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
+}
+
+void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const double *hs,
+                  const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
+                  int n_zones, double dt, int *step_ptr, int *flags, int mode, hipStream_t st) {
+    const int nb = n_zones > 0 ? blocks_for_waves(n_zones) : 1;
+    hipLaunchKernelGGL(k_zones, dim3(nb), dim3(256), 0, st, zone_off, entries, T, hs, a0, b0, zone_vol, zone_T,
+                       partial, n_zones, dt, step_ptr, flags, mode);
+}
+
+void launch_zone_update(const double *gathered, int n_blocks, const double *a0, const double *b0,
+                        const double *zone_vol, double *zone_T, int n_zones, double dt, int *step_ptr,
+                        int *flags, hipStream_t st) {
+    const int nb = n_zones > 0 ? (n_zones + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_zone_update, dim3(nb), dim3(256), 0, st, gathered, n_blocks, a0, b0, zone_vol, zone_T,
+                       n_zones, dt, step_ptr, flags);
+}
+
+void launch_nodes_fast(int M, const FastTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
+                       const int64_t *first_slot, double *state, int to_state, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    const dim3 grid(blocks_for_waves(n_tiles)), block(256);
+    switch (M) {
+    case 4: hipLaunchKernelGGL(k_nodes_fast<4>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state); break;
+    case 8: hipLaunchKernelGGL(k_nodes_fast<8>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state); break;
+    default: hipLaunchKernelGGL(k_nodes_fast<16>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state); break;
+    }
+}
+
+void launch_nodes_general(const GeneralTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
+                          const int64_t *first_slot, double *state, int to_state, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_nodes_general, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, Tbuf,
+                       meta, first_slot, state, to_state);
+}
+
+void launch_surf_scalars(int n_surf, const SlotArrays &sl, const SurfArrays &sa, double *solar_f, double *solar_b,
+                         double *ir_f, double *ir_b, double *state, int to_state, int what, hipStream_t st) {
+    if (n_surf <= 0) return;
+    hipLaunchKernelGGL(k_surf_scalars, dim3((n_surf + 255) / 256), dim3(256), 0, st, n_surf, sl, sa, solar_f,
+                       solar_b, ir_f, ir_b, state, to_state, what);
+}
+
+void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, double *state, int to_state,
+                         hipStream_t st) {
+    if (n_zones <= 0) return;
+    hipLaunchKernelGGL(k_zone_scalars, dim3((n_zones + 255) / 256), dim3(256), 0, st, n_zones, zone_slot, zone_T,
+                       state, to_state);
+}
+
+void launch_set_step(int *step_ptr, int v, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, step_ptr, v);
+}
+
+}  // namespace heat

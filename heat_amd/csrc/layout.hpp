@@ -1,0 +1,93 @@
+// layout.hpp — device data layout of a heat batch.
+//
+// All surfaces of a model are re-ordered into *groups* and *tiles*:
+//
+//   fast group (one per blocking factor M in {4, 8, 16})
+//     tile  = the work of one 64-lane wavefront: G surfaces of k lanes each
+//             (k = ceil(n / M) lanes per surface, G <= floor(64 / k));
+//             lane l of the tile holds nodes [seg*M, seg*M + M) of surface l / k,
+//             seg = l % k.
+//     node arrays (T, V = dt/mass, U) of a tile are stored lane-blocked:
+//             element (pair jp in [0, M/2), lane l) is a double2 at
+//             node_base + (jp * Lk + l) * 2,   Lk = floor(64 / k) * k
+//             so one wave instruction moves Lk * 16 contiguous bytes.
+//   general group (catch-all: any chunk structure, cavities, per-node alphas)
+//     tile  = 64 surfaces, one per lane; node j of lane l at node_base + j * 64 + l.
+//
+// Per-surface scalars are plain structure-of-arrays indexed by the device
+// surface number d (tiles own contiguous ranges of d).
+#pragma once
+#include <stdint.h>
+
+namespace heat {
+
+constexpr int kWave = 64;
+constexpr double kSigma = 5.670374419e-8;  // reference src/lib.rs:49
+constexpr double kMassThreshold = 1e-5;    // reference src/discretization.rs:149,155
+
+enum : int { KIND_SPACE = 0, KIND_AMBIENT = 1, KIND_OUTDOOR = 2 };
+
+// Device-side numerical flags (OR-ed).
+enum : int { FLAG_NAN_HS = 1, FLAG_NAN_NOMASS = 2, FLAG_NAN_ZONE = 4, FLAG_UNREACHABLE = 8 };
+
+struct FastTile {
+    int64_t node_base;  // in doubles, into the unified node buffers
+    int32_t surf_base;  // first device surface of the tile
+    int16_t k;          // lanes per surface
+    int16_t G;          // surfaces in this tile
+};
+
+struct GeneralTile {
+    int64_t node_base;  // in doubles
+    int32_t surf_base;
+    int32_t G;          // surfaces in this tile (<= 64)
+    int32_t n_max;      // max node count in the tile
+    int32_t pad;
+    int64_t scratch_base;  // in doubles, into the scratch buffer; [array][n_max][64]
+};
+
+// Per-surface structure of arrays (device pointers), indexed by device surface d.
+struct SurfArrays {
+    // packed: n_nodes | front_kind << 16 | back_kind << 18 | flags << 20
+    const int32_t *meta;
+    const int32_t *front_zone, *back_zone;
+    const double *front_ambient, *back_ambient;
+    const double *front_emis, *back_emis;
+    const double *area, *perimeter;
+    const double *cos_tilt, *normal_x, *normal_y, *wind_mod;
+    const double *alpha_f0, *alpha_bn;      // opaque shortcut: absorptance of first / last node
+    const double *hs_fix_f, *hs_fix_b;      // nullable
+    // inputs written by other modules between marches
+    const double *solar_f, *solar_b, *ir_f, *ir_b;
+    // outputs
+    double *hs_f, *hs_b, *flow_f, *flow_b;
+};
+
+// Unified per-node buffers (all groups).
+struct NodeArrays {
+    double *T;               // node temperatures (state)
+    const double *V;         // dt / mass for massive nodes, 0 for no-mass and padding
+    const double *U;         // Solid u, 0 for Back/padding (cavity segments: 0, see cav)
+    const double *alpha_f;   // general group only (same indexing), else nullptr
+    const double *alpha_b;
+    const int32_t *cav;      // general group only: cavity index or -1
+    const double *mass;      // general group only: raw thermal mass
+};
+
+struct CavityDev {
+    double thickness, height, angle, eout, ein;
+    int32_t gas, pad;
+};
+
+// Weather and per-march constants, device-resident. step is advanced by the zone kernel.
+struct StepWeather {
+    double t_out, wind_speed, sin_wd, cos_wd;
+};
+
+struct ZoneEntry {
+    uint32_t t_index;   // index into NodeArrays::T of the face node
+    uint32_t hs_index;  // index into the concatenated [hs_f | hs_b] buffer
+    double area;
+};
+
+}  // namespace heat

@@ -1,0 +1,210 @@
+/*
+ * heat_amd.h — C ABI of the MI355X-native wall heat-conduction path.
+ *
+ * This is the drop-in boundary for the hot path of SIMPLE-BuildingSimulation/heat
+ * (reference paths below are relative to the reference repository root):
+ *
+ *   ThermalModel::new + allocate_memory   src/model.rs:193-354   -> heat_batch_create
+ *   ThermalModel::march (sub-dt loop)      src/model.rs:359-427   -> heat_batch_march
+ *   iterate_surfaces                       src/model.rs:102-180   -> (inside march) heat_batch_step_surfaces
+ *   calculate_zones_abc + estimate_zones_future_temperatures
+ *                                          src/model.rs:489-597,650-674 -> heat_batch_step_zones
+ *   SurfaceTrait::{get,set}_node_temperatures & the scalar slot accessors
+ *                                          src/surface_trait.rs:81-164 -> heat_batch_upload_state / _download_state
+ *
+ * The caller (a Rust shim implementing `SimulationModel for GpuThermalModel`,
+ * see INTEGRATION.md) keeps owning the flat `SimulationState` array; this
+ * library owns a device-resident mirror of the slots the path touches, laid out
+ * as a lane-blocked structure of arrays in HBM.
+ *
+ * Plain C types only. Every function returns 0 on success, a negative
+ * HEAT_E_* code for an invalid call/descriptor, or a positive HEAT_N_* code
+ * for a numerical failure detected on the device (the reference panics there).
+ * heat_last_error() returns a human-readable message for the last failure on
+ * the calling thread. The library never aborts the process.
+ */
+#ifndef HEAT_AMD_H
+#define HEAT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEAT_AMD_ABI_VERSION 1
+
+/* simple_model::Boundary as consumed at src/surface.rs:611-702 */
+enum heat_boundary_kind {
+    HEAT_BOUNDARY_SPACE = 0,
+    HEAT_BOUNDARY_AMBIENT = 1, /* Boundary::AmbientTemperature { temperature } */
+    HEAT_BOUNDARY_OUTDOOR = 2,
+    HEAT_BOUNDARY_GROUND = 3   /* rejected: the reference panics (surface.rs:642,687; model.rs:92) */
+};
+
+/* src/gas.rs:45-74 */
+enum heat_gas { HEAT_GAS_AIR = 0, HEAT_GAS_ARGON = 1, HEAT_GAS_KRYPTON = 2, HEAT_GAS_XENON = 3 };
+
+enum heat_status {
+    HEAT_OK = 0,
+    /* invalid call / descriptor (reference: Err(String) or a setup-time panic) */
+    HEAT_E_INVALID_ARG = -1,
+    HEAT_E_GROUND_BOUNDARY = -2, /* surface.rs:642,687 */
+    HEAT_E_UVALUE_NONE = -3,     /* discretization.rs:53 */
+    HEAT_E_SIZE = -4,            /* slot or index out of range */
+    HEAT_E_DEVICE = -5,          /* HIP runtime failure (message has the HIP error string) */
+    HEAT_E_TOO_MANY_NODES = -6,
+    /* numerical failure on the device (reference: assert!/unreachable! panics) */
+    HEAT_N_NAN_HS = 1,           /* surface.rs:704-707 */
+    HEAT_N_NAN_NOMASS = 2,       /* surface.rs:850 */
+    HEAT_N_NAN_ZONE = 3,         /* model.rs:417-420 */
+    HEAT_N_UNREACHABLE = 4       /* convection.rs:104, gas.rs:219,296 */
+};
+
+/* src/cavity.rs:28-50 */
+typedef struct heat_cavity {
+    double thickness;
+    double height;
+    double angle; /* radians; 0 horizontal, pi/2 vertical */
+    double eout;
+    double ein;
+    int32_t gas;  /* enum heat_gas */
+    int32_t reserved;
+} heat_cavity;
+
+/* Weather of one sub-timestep (model.rs:371-382). The shim converts degrees to radians
+ * (`wind_direction.to_radians()`, model.rs:373). */
+typedef struct heat_weather {
+    double dry_bulb;       /* C */
+    double wind_direction; /* radians */
+    double wind_speed;     /* m/s */
+} heat_weather;
+
+/*
+ * Everything ThermalModel::new derives and the hot path reads, flattened.
+ * Surfaces first, then fenestrations (the reference iterates them in that
+ * order, model.rs:388-408). All arrays are host memory, copied by
+ * heat_batch_create; they need not outlive the call.
+ */
+typedef struct heat_batch_desc {
+    int32_t abi_version; /* HEAT_AMD_ABI_VERSION */
+    int32_t reserved;
+    int64_t n_surfaces;
+    int64_t n_zones;
+    int64_t n_cavities;
+    int64_t n_state; /* length of the caller's SimulationState array */
+    double dt;       /* ThermalModel::dt, model.rs:76,326-330 */
+
+    /* Discretization::segments, CSR over surfaces (discretization.rs:73) */
+    const int64_t *node_offset; /* [n_surfaces+1] */
+    const double *mass;         /* segments[i].0 ; a node is massive iff mass >= 1e-5 (discretization.rs:149) */
+    const double *uvalue;       /* UValue::Solid(u) -> u ; UValue::Back -> 0 ; NaN = UValue::None (rejected) */
+    const int32_t *seg_cavity;  /* UValue::Cavity -> index into cavities, else -1 ; NULL when n_cavities == 0 */
+    const double *front_alpha;  /* ThermalSurfaceData::front_alphas, surface.rs:366 */
+    const double *back_alpha;   /* ThermalSurfaceData::back_alphas, surface.rs:370 */
+    const heat_cavity *cavities;
+
+    /* ThermalSurfaceData fields, surface.rs:315-381 */
+    const int32_t *front_kind, *back_kind; /* enum heat_boundary_kind */
+    const int32_t *front_zone, *back_zone; /* front/back_space_index (used when kind == SPACE) */
+    const double *front_ambient, *back_ambient; /* used when kind == AMBIENT */
+    const double *front_emissivity, *back_emissivity;
+    const double *area, *perimeter;
+    const double *cos_tilt;
+    const double *normal_x, *normal_y;
+    const double *wind_modifier;
+    const double *front_hs_fix, *back_hs_fix; /* debug-only overrides, surface.rs:374-380; NULL or NaN = none */
+
+    /* SimulationState slots (surface.rs:428-442; surface_trait.rs:223-378) */
+    const int64_t *first_node_slot; /* node slots of a surface are contiguous */
+    const int64_t *hs_front_slot, *hs_back_slot;
+    const int64_t *flow_front_slot, *flow_back_slot;
+    const int64_t *solar_front_slot, *solar_back_slot;
+    const int64_t *ir_front_slot, *ir_back_slot;
+
+    /* ThermalZone (zone.rs:28-56) */
+    const double *zone_volume;
+    const int64_t *zone_slot; /* Space dry-bulb temperature slot */
+} heat_batch_desc;
+
+typedef struct heat_batch heat_batch;
+
+/* Options for heat_batch_create_ex. Zero-initialise for defaults. */
+typedef struct heat_batch_options {
+    int32_t device;          /* HIP device ordinal; -1 = current device */
+    int32_t force_general;   /* 1: route every surface through the general (catch-all) kernel */
+    int32_t nodes_per_lane;  /* 0 = auto; else 4, 8 or 16 (fast-path blocking factor) */
+    int32_t use_graph;       /* 1: replay the sub-timestep as a hipGraph inside heat_batch_march */
+    void *stream;            /* hipStream_t to run on; NULL = a stream owned by the batch */
+    /* Multi-GPU (one process per GPU): this rank holds a shard of the surfaces but all zones.
+     * With n_ranks > 1 heat_batch_march is unavailable; the caller alternates
+     * heat_batch_step_surfaces -> all-gather of heat_batch_zone_partials -> heat_batch_step_zones. */
+    int32_t n_ranks;
+    int32_t rank;
+} heat_batch_options;
+
+/* ≙ ThermalModel::new + allocate_memory: validates, packs and uploads the constants. */
+int heat_batch_create(const heat_batch_desc *desc, heat_batch **out);
+int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *opt, heat_batch **out);
+void heat_batch_destroy(heat_batch *b);
+
+/* Copies every slot the path touches (node temperatures, hs, flows, irradiances, zone
+ * dry-bulb) from / to the caller's SimulationState. */
+int heat_batch_upload_state(heat_batch *b, const double *state, size_t n_state);
+int heat_batch_download_state(heat_batch *b, double *state, size_t n_state);
+/* Only what other modules write between two march calls: solar + IR irradiance slots
+ * and zone dry-bulb temperatures. */
+int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state);
+
+/*
+ * ≙ ThermalModel::march (model.rs:359-427): n_sub sub-timesteps.
+ * zone_a0 / zone_b0 (nullable, [n_zones]) are the terms of calculate_zones_abc that do
+ * not come from surfaces (HVAC, luminaires, infiltration, ventilation; model.rs:500-544),
+ * evaluated by the caller.
+ * Uploads the inputs from `state`, marches, downloads the outputs into `state`.
+ */
+int heat_batch_march(heat_batch *b, double *state, size_t n_state, const heat_weather *weather,
+                     int32_t n_sub, const double *zone_a0, const double *zone_b0);
+
+/* Same, but on the device-resident state only (no host traffic; asynchronous on the batch's
+ * stream until heat_batch_synchronize / a download). */
+int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_t n_sub,
+                              const double *zone_a0, const double *zone_b0);
+int heat_batch_synchronize(heat_batch *b); /* waits, then reports device-side numerical flags */
+
+/* Split-phase sub-timestep, for the sharded (multi-GPU) case. All asynchronous on the stream.
+ * step_surfaces ≙ iterate_surfaces over this rank's surfaces + this rank's partial (a,b) sums.
+ * step_zones    ≙ the zone update from `gathered` = n_ranks consecutive partial blocks
+ *                 (device pointer, layout [rank][2][n_zones]: a then b), summed in rank order. */
+int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n_sub,
+                           const double *zone_a0, const double *zone_b0);
+int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step);
+int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks);
+double *heat_batch_zone_partials(heat_batch *b); /* device pointer, [2][n_zones] doubles */
+
+/* Introspection (tests, bench). */
+int64_t heat_batch_n_surfaces(const heat_batch *b);
+int64_t heat_batch_n_nodes(const heat_batch *b);
+int64_t heat_batch_n_zones(const heat_batch *b);
+/* Bytes one sub-timestep must move at minimum: 32 B per node + per-surface scalars. */
+int64_t heat_batch_algorithmic_bytes(const heat_batch *b);
+/* Total iterations of the no-mass fixed-point loop (surface.rs:808-896) since creation. */
+int64_t heat_batch_nomass_iterations(heat_batch *b);
+/* Number of surfaces routed to {fast M=4, M=8, M=16, general}. */
+int heat_batch_class_counts(const heat_batch *b, int64_t counts[4]);
+/* Kernel timing with HIP events recorded on the batch's stream around the surface kernels of
+ * every sub-timestep executed while enabled (the march then runs eagerly, not as a graph).
+ * heat_batch_get_timing synchronises and returns the mean duration in microseconds of the
+ * surface kernels of one sub-timestep (*surf_us), of one whole sub-timestep (*substep_us) and
+ * the number of sub-timesteps sampled; it then clears the samples. */
+int heat_batch_set_timing(heat_batch *b, int32_t enabled);
+int heat_batch_get_timing(heat_batch *b, double *surf_us, double *substep_us, int64_t *n_samples);
+
+const char *heat_last_error(void);
+int heat_amd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

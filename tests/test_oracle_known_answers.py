@@ -1,0 +1,368 @@
+"""Pins the CPU oracle (oracle/heat_oracle.c) against the reference's own known-answer tests.
+
+Each test re-types the constants of one reference test and cites it (paths relative to the
+reference repository). CPU only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from helpers import BRICKWORK, POLYURETHANE, surfaces_model
+from heat_amd import modeldict as mdl
+
+
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---------------------------------------------------------------- surface.rs:1558-1620
+def test_rk4_closed_form(oracle):
+    L = oracle.lib()
+    c = np.array([1., 1.])
+    lo = np.array([0., 4.])      # K = [[1,-3],[4,-6]]
+    dg = np.array([1., -6.])
+    up = np.array([-3., 0.])
+    q = np.zeros(2)
+    temps = np.array([0.75 + 1., 2.])
+    dt = 0.01
+    L.or_rearrange_k(2, dt, dp(c), dp(lo), dp(dg), dp(up), dp(q))
+    time = 0.0
+    worst = 0.0
+    while True:
+        ea = 0.75 * math.exp(-3. * time) + math.exp(-2. * time)
+        eb = math.exp(-3. * time) + math.exp(-2. * time)
+        worst = max(worst, abs(temps[0] - ea), abs(temps[1] - eb))
+        assert abs(temps[0] - ea) < 1e-8 and abs(temps[1] - eb) < 1e-8  # SMOL, surface.rs:1595
+        L.or_rk4(2, dp(lo), dp(dg), dp(up), dp(q), dp(temps))
+        time += dt
+        if time > 100.:
+            break
+    assert worst < 1e-8
+
+
+# ---------------------------------------------------------------- discretization.rs:1061-1469
+def _solid_system(oracle, thermal_cond, masses):
+    n = 5
+    u = thermal_cond / (0.5 / n)
+    uvalue = np.array([u] * n + [0.0])
+    temps = np.array([1., 2., 3., 4., 5., 6.])
+    return n, u, uvalue, temps
+
+
+def _get_k_q(oracle, uvalue, temps, ini, fin, fenv, fhs, benv, bhs):
+    L = oracle.lib()
+    nn = fin - ini
+    lo, dg, up, q = (np.zeros(nn) for _ in range(4))
+    rc = L.or_get_k_q(len(uvalue), dp(uvalue), None, None, ini, fin, dp(temps),
+                      fenv[0], fenv[1], fhs, 1.0, benv[0], benv[1], bhs, 1.0, dp(lo), dp(dg), dp(up), dp(q))
+    assert rc == 0
+    return lo, dg, up, q
+
+
+def _tarp_hs(oracle):
+    # get_solid_test_system, discretization.rs:1061-1108: default env has surface T = 22, cos_tilt = 0
+    L = oracle.lib()
+    err = C.c_int(0)
+    front_hs = L.or_tarp_natural(0., 22., 0.0, C.byref(err))
+    back_hs = L.or_tarp_total(7., 22., 0.0, 0., 1., 4., 0, C.byref(err))
+    assert err.value == 0
+    return front_hs, back_hs
+
+
+def test_get_q_k_solid(oracle):  # discretization.rs:1111-1191
+    n, u, uvalue, temps = _solid_system(oracle, 2.12, None)
+    fhs, bhs = _tarp_hs(oracle)
+    lo, dg, up, q = _get_k_q(oracle, uvalue, temps, 0, n + 1, (0., 0.), fhs, (7., 5.), bhs)
+    assert q[0] < -1e-5 and q[n] > 1e-5 and np.all(np.abs(q[1:n]) < 1e-29)
+    assert abs(dg[0] - (-fhs - u)) < 1e-20
+    assert abs(dg[n] - (-bhs - u)) < 1e-20
+    assert np.all(np.abs(dg[1:n] - (-2. * u)) < 1e-20)
+    assert np.all(np.abs(up[:n] - u) < 1e-20) and np.all(np.abs(lo[1:] - u) < 1e-20)
+
+
+def test_get_q_k_solid_partial(oracle):  # discretization.rs:1193-1275
+    n, u, uvalue, temps = _solid_system(oracle, 2.12, None)
+    fhs, bhs = _tarp_hs(oracle)
+    lo, dg, up, q = _get_k_q(oracle, uvalue, temps, 0, 3, (0., 0.), fhs, (7., 5.), bhs)
+    assert q[0] < -1e-5 and q[2] > 1e-5 and abs(q[1]) < 1e-29
+    assert abs(dg[0] - (-fhs - u)) < 1e-20
+    assert abs(dg[1] - (-2. * u)) < 1e-20 and abs(dg[2] - (-2. * u)) < 1e-20
+    assert np.all(np.abs(up[:2] - u) < 1e-20) and np.all(np.abs(lo[1:] - u) < 1e-20)
+
+
+def test_get_q_k_solid_partial_2(oracle):  # discretization.rs:1277-1359
+    n, u, uvalue, temps = _solid_system(oracle, 0.1, None)
+    fhs, bhs = _tarp_hs(oracle)
+    lo, dg, up, q = _get_k_q(oracle, uvalue, temps, 2, 5, (0., 0.), fhs, (7., 5.), bhs)
+    assert abs(q[1]) < 1e-29 and abs(q[0]) > 1e-3 and abs(q[2]) > 1e-3
+    assert np.all(np.abs(dg - (-2. * u)) < 1e-20)
+    assert np.all(np.abs(up[:2] - u) < 1e-20) and np.all(np.abs(lo[1:] - u) < 1e-20)
+
+
+def test_get_q_k_partial(oracle):  # discretization.rs:1361-1469
+    n = 5
+    u = 1. / (0.5 / n)
+    uvalue = np.array([u] * n + [0.0])
+    temps = np.array([1., 2., 3., 4., 5., 6.])
+    hs = 1.739658084820765
+    lo, dg, up, q = _get_k_q(oracle, uvalue, temps, 1, n, (1., 0.), hs, (6., 5.), hs)
+    assert q[0] > 1e-5 and q[n - 2] > 1e-5 and np.all(np.abs(q[1:n - 2]) < 1e-29)
+    assert np.all(np.abs(dg - (-2. * u)) < 1e-20)
+    assert np.all(np.abs(up[:n - 2] - u) < 1e-20) and np.all(np.abs(lo[1:] - u) < 1e-20)
+
+
+def test_get_chunks(oracle):  # discretization.rs:1471-1558
+    gc = oracle.get_chunks
+    assert gc([1.]) == ([(0, 1)], [])
+    assert gc([0.]) == ([], [(0, 1)])
+    assert gc([1.] * 10) == ([(0, 10)], [])
+    assert gc([0.] * 10) == ([], [(0, 10)])
+    assert gc([0., 1., 1., 0., 0.]) == ([(1, 3)], [(0, 1), (3, 5)])
+    assert gc([1., 1., 1., 0., 0.]) == ([(0, 3)], [(3, 5)])
+
+
+# ---------------------------------------------------------------- discretization.rs:756-1058
+def test_build_normal_mass_and_no_mass(oracle):
+    k, rho, cp, th = 1., 2.1, 1.312, 12.5 / 1000.
+    lay = [dict(thickness=th, k=k, rho=rho, cp=cp)]
+    d = oracle.build_segments(lay, [1])
+    assert d["n_nodes"] == 2
+    assert abs(d["mass"][0] - th * rho * cp / 2.) < 1e-17 and abs(d["mass"][1] - th * rho * cp / 2.) < 1e-17
+    assert abs(d["uvalue"][0] - k / th) < 1e-16 and d["uvalue"][1] == 0.0
+    d = oracle.build_segments(lay, [0])
+    assert d["n_nodes"] == 2 and np.all(np.abs(d["mass"]) < 1e-17)
+    assert abs(d["uvalue"][0] - k / th) < 1e-16 and d["uvalue"][1] == 0.0
+
+
+def test_build_normal_gas_normal(oracle):
+    k, rho, cp, th = 1., 2.1, 1.312, 12.5 / 1000.
+    solid = dict(thickness=th, k=k, rho=rho, cp=cp, front_thermal_abs=0.9, back_thermal_abs=0.8)
+    gas = dict(thickness=th, is_gas=True, gas=oracle.AIR)
+    for n_el, exp_mass in (([1, 1, 1], th * rho * cp / 2.), ([0, 0, 0], 0.0)):
+        d = oracle.build_segments([solid, gas, solid], n_el)
+        assert d["n_nodes"] == 4
+        assert np.all(np.abs(d["mass"] - exp_mass) < 1e-17)
+        assert abs(d["uvalue"][0] - k / th) < 1e-16 and abs(d["uvalue"][2] - k / th) < 1e-16
+        assert d["seg_cavity"][1] == 0 and d["seg_cavity"][0] == -1 and d["uvalue"][3] == 0.0
+        c = d["cavities"][0]
+        assert c["eout"] == 0.8 and c["ein"] == 0.9 and c["thickness"] == th  # discretization.rs:266-283
+
+
+# ---------------------------------------------------------------- gas.rs:334-511
+def test_gas_properties(oracle):
+    L = oracle.lib()
+
+    def close(a, b):
+        assert abs(a - b) / abs(a) <= 1e-2
+
+    for gas, exp in ((oracle.AIR, (0.0241, 0.0248)), (oracle.ARGON, (0.0163, 0.0169)),
+                     (oracle.KRYPTON, (0.0087, 0.0089)), (oracle.XENON, (0.0052, 0.0053))):
+        close(exp[0], L.or_gas_thermal_conductivity(gas, 273.15))
+        close(exp[1], L.or_gas_thermal_conductivity(gas, 283.15))
+    for gas, exp in ((oracle.AIR, (1.722e-5, 1.771e-5)), (oracle.ARGON, (2.1e-5, 2.165e-5)),
+                     (oracle.KRYPTON, (2.346e-5, 2.423e-5)), (oracle.XENON, (2.132e-5, 2.206e-5))):
+        close(exp[0], L.or_gas_dynamic_viscosity(gas, 273.15))
+        close(exp[1], L.or_gas_dynamic_viscosity(gas, 283.15))
+    for gas, exp in ((oracle.AIR, (1006.1034, 1006.2265)), (oracle.ARGON, (521.9285, 521.9285)),
+                     (oracle.KRYPTON, (248.0907, 248.0907)), (oracle.XENON, (158.3397, 158.3397))):
+        close(exp[0], L.or_gas_heat_capacity(gas, 273.15))
+        close(exp[1], L.or_gas_heat_capacity(gas, 283.15))
+    for gas, m in ((oracle.AIR, 28.97), (oracle.ARGON, 39.948), (oracle.KRYPTON, 83.80), (oracle.XENON, 131.3)):
+        close(m, L.or_gas_mass(gas))
+    assert abs(1.2041 - L.or_gas_density(oracle.AIR, 293.15)) < 1e-3
+
+
+NUSSELT = [  # (ra, a_gi, [(gamma_deg, expected)]) — gas.rs:406-511 (LBNL Windows-CalcEngine values)
+    (3638.21667064528, 83.3333333333333,
+     [(30., 1.40474349200254), (60., 1.08005742342789), (73., 1.05703042079892), (90., 1.02691818659179),
+      (134., 1.01936332296842)]),
+    (140.779077041012, 200.,
+     [(30., 1.), (60., 1.00002777439094), (73., 1.00002235511865), (90., 1.00001526837795),
+      (134., 1.00001098315195)]),
+    (4633340.8866717, 10.,
+     [(30., 10.2680981545288), (60., 11.5975502261096), (73., 11.4398529673101), (90., 11.2336334750340),
+      (134., 8.361460)]),
+]
+
+
+def test_nusselt_known_answers(oracle):
+    L = oracle.lib()
+    for ra, a_gi, cases in NUSSELT:
+        for deg, exp in cases:
+            err = C.c_int(0)
+            nu = L.or_nusselt(ra, deg * (math.pi / 180.), a_gi, C.byref(err))
+            assert err.value == 0
+            assert abs(nu - exp) < 1e-5, (ra, deg, nu, exp)
+
+
+def test_cavity_u_value_runs(oracle):  # cavity.rs:75-94 (the reference only prints)
+    c = oracle.Cavity(0.0127, 1., math.pi / 2., 0.84, 0.84, oracle.AIR, 0)
+    err = C.c_int(0)
+    u = oracle.lib().or_cavity_u_value(C.byref(c), 259.116115 - 273.15, 279.323983 - 273.15, C.byref(err))
+    assert err.value == 0 and 1.0 < u < 10.0
+    assert abs(u - 0.069446 / 0.0127) / u < 0.15  # the WINDOW value the reference prints next to it
+
+
+# ---------------------------------------------------------------- glazing.rs:432-523
+def test_iso9050_identities(oracle):
+    L = oracle.lib()
+    tau = np.array([0.1, 0.21, 0.21])
+    rf = np.array([0.13, 0.1123, 0.1123])
+    rb = np.array([0.3, 0.34, 0.34])
+    tau1, tau2, tau3 = tau
+    rho_f1, rho_f2, rho_f3 = rf
+    rho_b1, rho_b2, rho_b3 = rb
+    out = np.zeros(5)
+    L.or_glazing_combine_layers(2, dp(tau), dp(rf), dp(rb), dp(out))
+    assert abs(out[0] - tau1 * tau2 / (1. - rho_b1 * rho_f2)) < 1e-15                      # eq. 2
+    assert abs(out[1] - (rho_f1 + tau1 * tau1 * rho_f2 / (1. - rho_b1 * rho_f2))) < 1e-15  # eq. 5
+    L.or_glazing_combine_layers(3, dp(tau), dp(rf), dp(rb), dp(out))
+    denom = (1. - rho_b1 * rho_f2) * (1. - rho_b2 * rho_f3) - tau2 ** 2 * rho_b1 * rho_f3
+    assert abs(out[0] - tau1 * tau2 * tau3 / denom) < 1e-15                                # eq. 3
+    exp = rho_f1 + (tau1 * tau1 * rho_f2 * (1. - rho_b2 * rho_f3) + tau1 * tau1 * tau2 * tau2 * rho_f3) / denom
+    assert abs(out[1] - exp) < 1e-15                                                       # eq. 6
+    g13_alpha_front = out[3]
+    alphas = np.zeros(3)
+    assert L.or_glazing_alphas(3, dp(tau), dp(rf), dp(rb), dp(alphas)) == 3
+    assert abs(alphas.sum() - g13_alpha_front) < 1e-15
+    a_f1, a_b1 = 1. - tau1 - rho_f1, 1. - tau1 - rho_b1
+    a_f2, a_b2 = 1. - tau2 - rho_f2, 1. - tau2 - rho_b2
+    a_f3 = 1. - tau3 - rho_f3
+    exp_a1 = a_f1 + (tau1 * a_b1 * rho_f2 * (1. - rho_b2 * rho_f3) + tau1 * tau2 * tau2 * a_b1 * rho_f3) / denom
+    exp_a2 = (tau1 * a_f2 * (1. - rho_b2 * rho_f3) + tau1 * tau2 * a_b2 * rho_f3) / denom
+    exp_a3 = (tau1 * tau2 * a_f3) / denom
+    assert abs(alphas[0] - exp_a1) < 1e-15 and abs(alphas[1] - exp_a2) < 1e-15 and abs(alphas[2] - exp_a3) < 1e-15  # eqs. 23-25
+
+
+def test_node_alphas_opaque_and_single_pane(oracle):  # surface.rs:466-537; glazing.rs:372-430
+    opaque = dict(thickness=0.2, k=0.816, rho=1700., cp=800., front_solar_abs=0.7, back_solar_abs=0.6)
+    d = oracle.discretize([opaque], 180., 0.04, 60.)
+    assert d["alpha_rc"] == 0
+    assert d["front_alpha"][0] == 0.7 and np.all(d["front_alpha"][1:] == 0.0)
+    # sic: the back system is built by the same code as the front one (glazing.rs:67-112) and
+    # alphas() returns alpha_FRONT of the only layer (glazing.rs:266-268): the back face absorbs
+    # with the front absorptance. Reproduced, not fixed.
+    assert d["back_alpha"][-1] == 0.7 and np.all(d["back_alpha"][:-1] == 0.0)
+    glass = dict(thickness=0.003, k=1.0, rho=2500., cp=840., tau=0.8, front_solar_abs=0.1, back_solar_abs=0.1)
+    d = oracle.build_segments([glass], [0])
+    assert d["alpha_rc"] == 0 and np.allclose(d["front_alpha"], [0.05, 0.05]) and np.allclose(d["back_alpha"], [0.05, 0.05])
+    # translucent / gas / translucent panics in the reference ("mixture", surface.rs:470-472)
+    gas = dict(thickness=0.0127, is_gas=True, gas=oracle.AIR)
+    d = oracle.build_segments([glass, gas, glass], [0, 0, 0])
+    assert d["alpha_rc"] == -20
+
+
+# ---------------------------------------------------------------- surface.rs:1087-1556
+def _brick_model(oracle, front_kind, back_kind, **kw):
+    lay = [dict(thickness=20. / 1000., **BRICKWORK)]
+    d = oracle.discretize(lay, 300.0, (20. / 1000.) / 2.0, 1.0, 1., 0.)
+    dt = 300.0 / d["tstep_subdivision"]
+    md, state = surfaces_model(d, dt, front_kind, back_kind, hs_fix=(10., 10.), **kw)
+    return md, state, d
+
+
+def test_march_massive_1(oracle):  # surface.rs:1087-1225
+    md, state, d = _brick_model(oracle, mdl.OUTDOOR, mdl.OUTDOOR)
+    assert oracle.get_chunks(d["mass"])[1] == []  # all massive
+    m = oracle.OracleModel(md)
+    v = mdl.SIGMA * (10. + 273.15) ** 4
+    q, counter = 9999000009.0, 0
+    while abs(q) > 0.00015:
+        state[md["ir_front_slot"]] = v
+        state[md["ir_back_slot"]] = v
+        rc, _ = m.iterate_surfaces(state, 0.0, 0.0, 10.)
+        assert rc == 0
+        q_in = state[md["flow_back_slot"][0]]
+        q_out = state[md["flow_front_slot"][0]]
+        assert abs(q_in - q_out) < 0.5 and q_in >= 0. and q_out >= 0.
+        q = q_in
+        counter += 1
+        assert counter < 9999999
+    nodes = state[mdl.node_slots(md)]
+    assert np.all(np.abs(nodes - 10.0) < 0.002)
+
+
+def test_march_massive_2(oracle):  # surface.rs:1227-1342
+    # The reference test builds the simple_model Surface with Ambient(30)/Outdoor boundaries, but
+    # ThermalSurface::new leaves front/back_boundary at Boundary::default() (surface.rs:551-552) and the
+    # test never calls set_front_boundary / set_back_boundary (only ThermalModel::new does,
+    # model.rs:278-279). The default boundary is Outdoor (tests/tilted/back.spl omits the exterior
+    # side), so what the reference test marches is an Outdoor/Outdoor wall.
+    md, state, d = _brick_model(oracle, mdl.OUTDOOR, mdl.OUTDOOR)
+    m = oracle.OracleModel(md)
+    change, counter, previous_q = 99.0, 0, -125.0
+    while abs(change) > 1e-10:
+        rc, _ = m.iterate_surfaces(state, 0.0, 0.0, 10.0)
+        assert rc == 0
+        q_front = state[md["flow_front_slot"][0]]
+        q_back = state[md["flow_back_slot"][0]]
+        state[md["ir_front_slot"]] = mdl.SIGMA * (10. + 273.15) ** 4
+        state[md["ir_back_slot"]] = mdl.SIGMA * (30. + 273.15) ** 4
+        change = abs(q_front - previous_q)
+        previous_q = q_front
+        counter += 1
+        assert counter < 99999
+    assert q_front > -1e-5 and q_back < 1e-5
+
+
+def _poly_model(oracle, back_kind, **kw):
+    th = 3. / 1000.
+    lay = [dict(thickness=th, **POLYURETHANE), dict(thickness=th, **POLYURETHANE)]
+    d = oracle.discretize(lay, 3.0, th / 7.0, 10.0, 1., 0.)
+    dt = 3.0 / d["tstep_subdivision"]
+    md, state = surfaces_model(d, dt, mdl.OUTDOOR, back_kind, hs_fix=(10., 10.), **kw)
+    return md, state, d
+
+
+def test_march_nomass(oracle):  # surface.rs:1344-1443
+    md, state, d = _poly_model(oracle, mdl.OUTDOOR)
+    assert oracle.get_chunks(d["mass"])[0] == []  # no massive chunk
+    m = oracle.OracleModel(md)
+    rc, iters = m.iterate_surfaces(state, 0.0, 0.0, 10.0)
+    assert rc == 0 and iters >= 1
+    nodes = state[mdl.node_slots(md)]
+    assert abs(nodes[0] - 10.0) < 0.2 and abs(nodes[-1] - 10.0) < 0.2
+    assert abs(state[md["flow_front_slot"][0]]) < 0.07 and abs(state[md["flow_back_slot"][0]]) < 0.07
+
+
+def test_march_nomass_2(oracle):  # surface.rs:1445-1556
+    # Outdoor/Outdoor for the same reason as test_march_massive_2.
+    md, state, d = _poly_model(oracle, mdl.OUTDOOR)
+    m = oracle.OracleModel(md)
+    rc, _ = m.iterate_surfaces(state, 0.0, 0.0, 10.0)
+    assert rc == 0
+    q_front = state[md["flow_front_slot"][0]]
+    q_back = state[md["flow_back_slot"][0]]
+    assert q_front > -3e-2 and q_back < 3e-2 and abs(q_front + q_back) < 0.08
+
+
+# ---------------------------------------------------------------- model.rs:695-732
+def test_calculate_zones_abc(oracle):
+    th = 0.02
+    d = oracle.discretize([dict(thickness=th, **POLYURETHANE)], 3600., 0.04, 60.)
+    md, state = surfaces_model(d, 1800., mdl.OUTDOOR, mdl.SPACE, n_zones=1, zone_volume=[40.], area=4.0,
+                               perimeter=8.0, cos_tilt=0.0, normal=(0., -1., 0.))
+    m = oracle.OracleModel(md)
+    a, b, c = m.zones_abc(state)
+    hi = state[md["hs_back_slot"][0]]
+    temp = state[md["first_node_slot"][0] + len(d["mass"]) - 1]
+    assert c[0] == oracle.lib().or_zone_mcp(40., 22.)
+    assert a[0] == 4.0 * hi * temp and b[0] == 4.0 * hi
+
+
+# ---------------------------------------------------------------- error behaviour
+def test_ground_boundary_is_an_error(oracle):
+    d = oracle.discretize([dict(thickness=0.02, **BRICKWORK)], 300., 0.01, 1.0)
+    md, state = surfaces_model(d, 10., mdl.GROUND, mdl.OUTDOOR)
+    rc, _ = oracle.OracleModel(md).iterate_surfaces(state, 0., 0., 10.)
+    assert rc == -1  # OR_ERR_GROUND (surface.rs:642 unreachable!, model.rs:92 unimplemented!)
+
+
+def test_nan_temperature_is_reported(oracle):
+    d = oracle.discretize([dict(thickness=0.02, **BRICKWORK)], 300., 0.01, 1.0)
+    md, state = surfaces_model(d, 10., mdl.OUTDOOR, mdl.OUTDOOR)
+    state[md["first_node_slot"][0]] = np.nan
+    rc, _ = oracle.OracleModel(md).iterate_surfaces(state, 0., 0., 10.)
+    assert rc > 0
