@@ -209,6 +209,7 @@ def uniform_massive(S, n, Z=None, dt=45.0, seed=20260401, identical=False, verti
     _fill_common(md, rng, S, Z, "vertical" if vertical else "outdoor_space")
     state = layout_state(md)
     if not identical:
+        perturb_initial_temperatures(md, state, rng)
         state[md["solar_front_slot"]] = rng.uniform(0, 800., S)
     set_ir_from_air(md, state, 10.0)
     return md, state
@@ -279,10 +280,25 @@ def ragged_mixed(S, Z=None, dt=45.0, seed=20260401, n_lo=8, n_hi=64):
     ba[last] = rng.uniform(0.1, 0.9, S)
     md["front_alpha"], md["back_alpha"] = fa, ba
     _fill_common(md, rng, S, Z, "mixed")
+    # The reference's no-mass update T <- (T + x(T))/2 applies long-wave radiation explicitly
+    # (discretization.rs:663-664) and diverges from step to step once 4 eps sigma T^3 exceeds about
+    # three times the other conductances of the node. Keep the no-mass faces in the convergent regime.
+    light = mixed | pure
+    md["front_emissivity"] = np.where(light, md["front_emissivity"] * (0.2 / 0.9), md["front_emissivity"])
+    md["back_emissivity"] = np.where(light, md["back_emissivity"] * (0.2 / 0.9), md["back_emissivity"])
     state = layout_state(md)
+    perturb_initial_temperatures(md, state, rng)
     state[md["solar_front_slot"]] = rng.uniform(0, 800., S)
     set_ir_from_air(md, state, 10.0)
     return md, state
+
+
+def perturb_initial_temperatures(md, state, rng):
+    """Spreads the initial temperatures (the reference's all-22.0 start makes every natural
+    convection coefficient hit its 0.1 floor, convection.rs:22,91-92)."""
+    ns = node_slots(md)
+    state[ns] = T_INIT + rng.uniform(-3.0, 3.0, len(ns))
+    state[md["zone_slot"]] = T_INIT + rng.uniform(-2.0, 2.0, int(md["n_zones"]))
 
 
 def glazing_cavity(S, Z=None, dt=45.0, seed=7, trombe_fraction=0.5):

@@ -1,0 +1,175 @@
+"""Parity of the HIP path (through the C ABI, heat_amd/lib/libheat_amd.so) against the CPU oracle.
+
+Tolerance: BASELINE.json's north_star asks for node temperatures within 1e-9 relative of the
+reference CPU path. Every comparison below uses rtol = 1e-9 with atol = 1e-9 (temperatures are in
+Celsius and cross zero, heat flows reach zero at equilibrium).
+"""
+import numpy as np
+import pytest
+
+from helpers import BRICKWORK, POLYURETHANE, surfaces_model
+from heat_amd import HeatBatch, HeatError
+from heat_amd import modeldict as mdl
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+ATOL = 1e-9
+
+
+def run_both(oracle, md, state0, weather, a0=None, b0=None, **opts):
+    ref = state0.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, weather, a0, b0)
+    assert rc == 0
+    got = state0.copy()
+    with HeatBatch(md, **opts) as b:
+        b.upload_state(got)
+        b.march(got, weather, a0, b0)
+        counts = b.class_counts()
+        gpu_iters = b.nomass_iterations()
+    return ref, got, iters, gpu_iters, counts
+
+
+def assert_state_close(md, ref, got):
+    for name, idx in (("nodes", mdl.node_slots(md)), ("hs_front", md["hs_front_slot"]), ("hs_back", md["hs_back_slot"]),
+                      ("flow_front", md["flow_front_slot"]), ("flow_back", md["flow_back_slot"]),
+                      ("zones", md["zone_slot"])):
+        r, g = ref[idx], got[idx]
+        err = np.abs(r - g) / (ATOL + RTOL * np.abs(r))
+        assert np.all(np.isfinite(g)), name
+        assert err.max() <= 1.0 if len(err) else True, "%s: worst |diff| %.3e at %d (ref %.17g, got %.17g)" % (
+            name, np.abs(r - g).max(), int(err.argmax()), r[err.argmax()], g[err.argmax()])
+    # slots the path does not own must be untouched
+    owned = np.zeros(len(ref), dtype=bool)
+    for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
+                md["flow_back_slot"], md["zone_slot"]):
+        owned[idx] = True
+    assert np.array_equal(ref[~owned], got[~owned])
+
+
+@pytest.mark.parametrize("npl", [0, 4, 8, 16])
+def test_config2_identical_massive_walls(oracle, npl):
+    # BASELINE config 2 at reduced S: identical 3-layer massive walls x 20 nodes, RK4 only
+    md, st = mdl.uniform_massive(300, 20, Z=3, dt=90.0, identical=True, vertical=True)
+    w = mdl.weather_series(60, 90.0)
+    ref, got, _, _, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
+    assert counts[3] == 0  # all on the fast path
+    assert_state_close(md, ref, got)
+
+
+@pytest.mark.parametrize("n,npl", [(32, 0), (32, 4), (32, 8), (7, 0), (13, 0), (64, 4), (33, 8), (2, 0), (50, 16)])
+def test_uniform_massive_random_materials(oracle, n, npl):
+    md, st = mdl.uniform_massive(517, n, Z=5, dt=45.0, seed=n * 7 + npl)
+    w = mdl.weather_series(40, 45.0, wind_speed=4.5, wind_deg=200.0)
+    ref, got, _, _, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
+    assert counts[3] == 0
+    assert_state_close(md, ref, got)
+
+
+def test_general_kernel_matches_fast_kernel_and_oracle(oracle):
+    md, st = mdl.uniform_massive(200, 24, Z=4, dt=45.0, seed=3)
+    w = mdl.weather_series(30, 45.0)
+    ref, got, _, _, counts = run_both(oracle, md, st, w, force_general=True)
+    assert counts[3] == 200
+    assert_state_close(md, ref, got)
+
+
+def test_config3_ragged_mixed(oracle):
+    # BASELINE config 3 at reduced S: ragged 8..64 nodes, massive / mixed / pure no-mass, all boundary kinds
+    md, st = mdl.ragged_mixed(3000, Z=30, dt=45.0, seed=20260401)
+    w = mdl.weather_series(25, 45.0)
+    a0 = np.linspace(0., 500., 30)
+    b0 = np.linspace(0., 20., 30)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, a0, b0)
+    assert counts[3] > 0 and sum(counts[:3]) > 0
+    assert iters == gpu_iters, "no-mass loop took a different number of passes (%d vs %d)" % (iters, gpu_iters)
+    assert_state_close(md, ref, got)
+
+
+def test_config5_glazing_and_cavities(oracle):
+    md, st = mdl.glazing_cavity(400, Z=8, dt=45.0)
+    w = mdl.weather_series(25, 45.0)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w)
+    assert counts[3] == 400
+    assert iters == gpu_iters
+    assert_state_close(md, ref, got)
+
+
+def test_reference_unit_test_walls_through_the_abi(oracle):
+    # test_march_massive_1 / test_march_nomass (surface.rs:1087-1443) with the debug hs overrides
+    lay = [dict(thickness=20. / 1000., **BRICKWORK)]
+    d = oracle.discretize(lay, 300.0, 0.01, 1.0, 1., 0.)
+    md, st = surfaces_model(d, 300.0 / d["tstep_subdivision"], mdl.OUTDOOR, mdl.OUTDOOR, hs_fix=(10., 10.), copies=3)
+    st[md["ir_front_slot"]] = mdl.SIGMA * 283.15 ** 4
+    st[md["ir_back_slot"]] = mdl.SIGMA * 283.15 ** 4
+    w = np.tile([10., 0., 0.], (400, 1))
+    ref, got, *_ = run_both(oracle, md, st, w)
+    assert_state_close(md, ref, got)
+    assert np.all(np.abs(got[mdl.node_slots(md)] - 10.0) < 0.5)
+
+    th = 3. / 1000.
+    d = oracle.discretize([dict(thickness=th, **POLYURETHANE)] * 2, 3.0, th / 7., 10.0, 1., 0.)
+    md, st = surfaces_model(d, 3.0 / d["tstep_subdivision"], mdl.OUTDOOR, mdl.OUTDOOR, hs_fix=(10., 10.), copies=2)
+    ref, got, iters, gpu_iters, _ = run_both(oracle, md, st, np.tile([10., 0., 0.], (3, 1)))
+    assert iters == gpu_iters
+    assert_state_close(md, ref, got)
+
+
+def test_march_equals_resident_march_plus_download(oracle):
+    md, st = mdl.ragged_mixed(500, Z=5, dt=45.0, seed=11)
+    w = mdl.weather_series(10, 45.0)
+    a = st.copy()
+    b_ = st.copy()
+    with HeatBatch(md) as b:
+        b.upload_state(a)
+        b.march(a, w)
+    with HeatBatch(md, use_graph=True) as b:
+        b.upload_state(b_)
+        b.march_resident(w[:4])
+        b.march_resident(w[4:])
+        b.synchronize()
+        b.download_state(b_)
+    assert np.array_equal(a, b_)  # same kernels, same order: bitwise equal
+
+
+def test_split_phase_steps_equal_fused_march(oracle):
+    md, st = mdl.ragged_mixed(400, Z=4, dt=45.0, seed=5)
+    w = mdl.weather_series(6, 45.0)
+    a = st.copy()
+    with HeatBatch(md) as b:
+        b.upload_state(a)
+        b.march(a, w)
+    c = st.copy()
+    with HeatBatch(md) as b:
+        b.upload_state(c)
+        b.set_weather(w)
+        for i in range(len(w)):
+            b.step_surfaces(i)
+            b.step_zones(None, 1)
+        b.synchronize()
+        b.download_state(c)
+    ref = st.copy()
+    oracle.OracleModel(md).march(ref, w)
+    assert_state_close(md, ref, c)
+    assert_state_close(md, a, c)
+
+
+def test_error_codes(oracle):
+    d = oracle.discretize([dict(thickness=0.02, **BRICKWORK)], 300., 0.01, 1.0)
+    md, st = surfaces_model(d, 10., mdl.GROUND, mdl.OUTDOOR)
+    with pytest.raises(HeatError) as e:
+        HeatBatch(md)
+    assert e.value.code == -2  # HEAT_E_GROUND_BOUNDARY
+    md, st = surfaces_model(d, 10., mdl.OUTDOOR, mdl.OUTDOOR)
+    md["uvalue"] = md["uvalue"].copy()
+    md["uvalue"][0] = np.nan
+    with pytest.raises(HeatError) as e:
+        HeatBatch(md)
+    assert e.value.code == -3  # HEAT_E_UVALUE_NONE
+    md, st = surfaces_model(d, 10., mdl.OUTDOOR, mdl.OUTDOOR)
+    st[md["first_node_slot"][0]] = np.nan
+    with HeatBatch(md) as b:
+        b.upload_state(st)
+        with pytest.raises(HeatError) as e:
+            b.march(st, np.array([[10., 0., 1.]]))
+        assert e.value.code > 0  # numerical failure, like the reference's panic
