@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X wall heat-conduction path.
+
+A *step* is one sub-timestep of ThermalModel::march (reference src/model.rs:369-424) over the
+whole batch: iterate_surfaces for every surface + the zone update. The workload is the
+north_star headline of BASELINE.json: 1 000 000 all-massive surfaces x 32 nodes per GPU
+(weak scaling: every rank holds its own million), RK4 + convection / long-wave / solar boundary
+updates, zones of 100 surfaces. State is resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the surface kernel's algorithmic GB/s (HIP events on the kernel's stream, recorded
+                inside the timed region) against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (oracle/, a C port of the reference path) timed on this box's host
+                cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def build_shard(S, n, zones_per_gpu, rank, world, dt, seed):
+    """This rank's million walls. Zones are global; zone boundaries are offset by half a zone so
+    that the first/last zone of every rank also has surfaces on the neighbouring rank."""
+    from heat_amd import modeldict as mdl
+    Z = zones_per_gpu * world
+    md, state = mdl.uniform_massive(S, n, Z=Z, dt=dt, seed=seed + rank)
+    g = rank * S + np.arange(S, dtype=np.int64)
+    per_zone = max(1, (S * world) // Z)
+    md["back_zone"] = (((g + per_zone // 2) // per_zone) % Z).astype(np.int32)
+    md["front_zone"] = md["back_zone"].copy()
+    return md, state
+
+
+def cpu_baseline(n, dt, seed, target_seconds=12.0):
+    """Times the oracle (single thread: the reference is single-threaded, model.rs:113-116) on a
+    bounded sample of the same workload."""
+    from heat_amd import modeldict as mdl
+    from oracle import oracle as orc
+    S_cpu, steps = 20000, 10
+    md, state = mdl.uniform_massive(S_cpu, n, Z=S_cpu // 100, dt=dt, seed=seed)
+    m = orc.OracleModel(md)
+    w = mdl.weather_series(steps, dt)
+    t0 = time.perf_counter()
+    rc, _ = m.march(state, w)
+    t1 = time.perf_counter() - t0
+    assert rc == 0
+    rate = S_cpu * n * steps / t1
+    # scale the sample up to ~target_seconds of CPU work
+    steps2 = int(max(steps, min(400, target_seconds * rate / (S_cpu * n))))
+    w = mdl.weather_series(steps2, dt)
+    t0 = time.perf_counter()
+    rc, _ = m.march(state, w)
+    t2 = time.perf_counter() - t0
+    assert rc == 0
+    out = {"value": S_cpu * n * steps2 / t2, "unit": "node-updates/s", "cores": 1, "kind": "port",
+           "sample": "%d surfaces x %d nodes x %d sub-timesteps of the same workload, %.1f s; "
+                     "tri-diagonal storage, no per-step allocation: an upper bound on the Rust reference's speed"
+                     % (S_cpu, n, steps2, t2)}
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = min(ncores, 16)  # the GPU box gives one GPU's share of the host: 16 cores
+    if ncores > 1:
+        st2 = state.copy()
+        t0 = time.perf_counter()
+        rc, _ = m.march(st2, w[:max(1, steps2 // 2)], threads=ncores)
+        t3 = time.perf_counter() - t0
+        out["all_cores"] = {"value": S_cpu * n * max(1, steps2 // 2) / t3, "cores": ncores,
+                            "note": "OpenMP over surfaces = the reference's disabled rayon path (model.rs:113-116)"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--surfaces", type=int, default=1_000_000, help="surfaces per GPU")
+    ap.add_argument("--nodes", type=int, default=32)
+    ap.add_argument("--zones-per-gpu", type=int, default=10_000)
+    ap.add_argument("--nodes-per-lane", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    K, W = args.steps, args.warmup
+    dt = 45.0
+    seed = 20260401
+
+    from heat_amd import HeatBatch, modeldict as mdl
+    md, state = build_shard(args.surfaces, args.nodes, args.zones_per_gpu, rank, world, dt, seed)
+    n_nodes_local = int(md["node_offset"][-1])
+    weather_w = mdl.weather_series(max(W, 1), dt)
+    weather_k = mdl.weather_series(K, dt, t0=dt * W)
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from heat_amd.sharded import ShardedMarch
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        sm = ShardedMarch(md, rank, world, device_index=local_rank, nodes_per_lane=args.nodes_per_lane)
+        batch = sm.batch
+        batch.upload_state(state)
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        run = sm.march_resident
+    else:
+        batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True)
+        batch.upload_state(state)
+
+        def barrier():
+            batch.synchronize()
+
+        run = batch.march_resident
+
+    if W > 0:
+        run(weather_w[:W])
+    barrier()
+    batch.set_timing(not args.no_timing)
+    t0 = time.perf_counter()
+    run(weather_k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    surf_us, substep_us, n_samples = batch.get_timing()
+    batch.set_timing(False)
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    algorithmic_bytes = batch.algorithmic_bytes
+    counts = batch.class_counts()
+    total_nodes = n_nodes_local * world
+    value = total_nodes * K / elapsed
+    result = {
+        "metric": "surface-node-updates/sec",
+        "value": value,
+        "unit": "node-updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "sub_timesteps_per_sec": K / elapsed,
+        "config": {
+            "workload": "north_star headline: %d all-massive surfaces x %d nodes per GPU, RK4 + TARP convection + "
+                        "long-wave + solar boundaries, %d zones per GPU, dt = %g s; one step = one sub-timestep "
+                        "(iterate_surfaces + zone update)" % (args.surfaces, args.nodes, args.zones_per_gpu, dt),
+            "surfaces_per_gpu": args.surfaces, "nodes_per_surface": args.nodes,
+            "zones_per_gpu": args.zones_per_gpu, "dt_s": dt,
+            "kernel_classes[M4,M8,M16,general]": counts,
+            "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep all-gather of zone partials" % world
+            if world > 1 else "single GPU",
+        },
+    }
+    if n_samples > 0:
+        achieved = algorithmic_bytes / (surf_us * 1e-6) / 1e9
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_surfaces_fast (iterate_surfaces: RK4 stencil + boundary updates)",
+            "algorithmic_bytes_per_launch": algorithmic_bytes,
+            "kernel_us": surf_us, "substep_us": substep_us, "samples": n_samples,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.nodes, dt, seed)
+    if world > 1:
+        import torch.distributed as dist
+        sm.close()
+        dist.destroy_process_group()
+    else:
+        batch.close()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

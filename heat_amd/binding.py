@@ -80,6 +80,7 @@ SYMBOLS = [
     ("heat_batch_step_surfaces", C.c_int, [_H, C.c_int32]),
     ("heat_batch_step_zones", C.c_int, [_H, C.c_void_p, C.c_int32]),
     ("heat_batch_zone_partials", C.c_void_p, [_H]),
+    ("heat_batch_use_partials", C.c_int, [_H, C.c_void_p]),
     ("heat_batch_n_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_nodes", C.c_int64, [_H]),
     ("heat_batch_n_zones", C.c_int64, [_H]),
@@ -272,6 +273,9 @@ class HeatBatch:
 
     def zone_partials_ptr(self):
         return self._L.heat_batch_zone_partials(self._h)
+
+    def use_partials(self, dev_ptr):
+        _check(self._L.heat_batch_use_partials(self._h, dev_ptr))
 
     def set_timing(self, enabled):
         _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))

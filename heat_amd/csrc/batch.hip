@@ -110,6 +110,7 @@ struct heat_batch {
     DevBuf<int64_t> d_zone_slot, d_zone_off;
     DevBuf<ZoneEntry> d_zone_entries;
     DevBuf<double> d_zone_vol, d_zone_T, d_zone_a0, d_zone_b0, d_partial;
+    double *partial_ptr = nullptr;  // where step_surfaces writes (a, b): d_partial or caller memory
     DevBuf<double> d_state;
     DevBuf<StepWeather> d_weather;
     DevBuf<int> d_step, d_flags;
@@ -169,8 +170,10 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
     if (n < 2) return 3;
     int M = opt.nodes_per_lane;
     if (M == 0) {
+        // Same padding (to a multiple of 4) either way; M = 8 halves the per-surface boundary work.
+        // M = 16 is only taken on request: its working set spills at 256 VGPRs (profiles/README.md).
         const int n4 = (n + 3) / 4 * 4;
-        M = (n4 % 16 == 0) ? 16 : (n4 % 8 == 0) ? 8 : 4;
+        M = (n4 % 8 == 0) ? 8 : 4;
     }
     const int k = (n + M - 1) / M;
     if (k > kWave) return 3;
@@ -253,7 +256,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     b->n_cav = d->n_cavities;
     b->dt = d->dt;
     b->n_nodes = S > 0 ? d->node_offset[S] : 0;
-    b->algorithmic_bytes = 32 * b->n_nodes + (136 + 32) * S;
+    b->algorithmic_bytes = 32 * b->n_nodes + 152 * S;  // 32 n + 152 bytes per surface per sub-timestep
 
     // ---- classify and order ----
     std::vector<Placed> placed(S);
@@ -496,6 +499,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_zone_a0.zeros(Z));
     HIP_TRY(b->d_zone_b0.zeros(Z));
     HIP_TRY(b->d_partial.zeros(2 * Z));
+    b->partial_ptr = b->d_partial.p;
     HIP_TRY(b->d_state.zeros(d->n_state));
     HIP_TRY(b->d_step.zeros(1));
     HIP_TRY(b->d_flags.zeros(1));
@@ -542,7 +546,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
 
 void enqueue_zones(heat_batch *b, int mode) {
     launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_hs.p, b->d_zone_a0.p, b->d_zone_b0.p,
-                 b->d_zone_vol.p, b->d_zone_T.p, b->d_partial.p, (int)b->n_zones, b->dt, b->d_step.p,
+                 b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
                  b->d_flags.p, mode, b->stream);
 }
 
@@ -737,20 +741,34 @@ int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step) {
     if (sub_step < 0 || sub_step >= b->n_weather) return fail(HEAT_E_INVALID_ARG, "sub_step %d outside the weather set (%d)", sub_step, b->n_weather);
     int rc = select_device(b);
     if (rc) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (b->timing) {
+        e0 = next_event(b); e1 = next_event(b); e2 = next_event(b);
+        if (!e0 || !e1 || !e2) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e0, b->stream));
+    }
     enqueue_surfaces(b, sub_step);
+    if (b->timing) HIP_TRY(hipEventRecord(e1, b->stream));
     enqueue_zones(b, 1);  // partial (a, b) of this rank's surfaces
+    if (b->timing) HIP_TRY(hipEventRecord(e2, b->stream));
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
 }
 
-double *heat_batch_zone_partials(heat_batch *b) { return b ? b->d_partial.p : nullptr; }
+double *heat_batch_zone_partials(heat_batch *b) { return b ? b->partial_ptr : nullptr; }
+
+int heat_batch_use_partials(heat_batch *b, double *partials_dev) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    b->partial_ptr = partials_dev ? partials_dev : b->d_partial.p;
+    return HEAT_OK;
+}
 
 int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
     if (n_blocks < 1) return fail(HEAT_E_INVALID_ARG, "n_blocks < 1");
     int rc = select_device(b);
     if (rc) return rc;
-    const double *g = gathered_dev ? gathered_dev : b->d_partial.p;
+    const double *g = gathered_dev ? gathered_dev : b->partial_ptr;
     launch_zone_update(g, n_blocks, b->d_zone_a0.p, b->d_zone_b0.p, b->d_zone_vol.p, b->d_zone_T.p,
                        (int)b->n_zones, b->dt, b->d_step.p, b->d_flags.p, b->stream);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,81 @@
+"""Multi-GPU plumbing: one process per GPU, surfaces sharded, zones replicated.
+
+Surfaces are independent inside a sub-timestep (reference src/model.rs:102-180); the only
+exchange is the zone heat balance ``a[z] = sum h A T_surf``, ``b[z] = sum h A`` over all surfaces
+touching zone z (src/model.rs:556-590). Each rank computes the partial sums of its own surfaces
+(``heat_batch_step_surfaces``), the partial blocks are all-gathered over RCCL/xGMI
+(``torch.distributed`` backend "nccl"; "gloo" on CPU in tests) and every rank applies the zone
+update from the blocks summed in rank order (``heat_batch_step_zones``) — so all replicas of the
+zone temperatures stay bitwise identical and the result does not depend on the collective's
+internal reduction order.
+"""
+import numpy as np
+
+
+def shard_ranges(n_surfaces, n_ranks):
+    """Contiguous, balanced surface ranges: rank r owns [bounds[r], bounds[r+1])."""
+    base, rem = divmod(int(n_surfaces), int(n_ranks))
+    sizes = [base + (1 if r < rem else 0) for r in range(n_ranks)]
+    return np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+
+
+def shard_model(md, rank, n_ranks):
+    """Model dict of this rank's surfaces; zones, state slots and n_state stay global."""
+    from . import modeldict as mdl
+    b = shard_ranges(md["n_surfaces"], n_ranks)
+    return mdl.subset(md, np.arange(b[rank], b[rank + 1]))
+
+
+class ZoneExchange:
+    """All-gather of the per-rank partial (a, b) blocks: [2 * n_zones] -> [n_ranks, 2 * n_zones]."""
+
+    def __init__(self, n_zones, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.partial = torch.zeros(2 * n_zones, dtype=torch.float64, device=device)
+        self.gathered = torch.zeros(self.world * 2 * n_zones, dtype=torch.float64, device=device)
+
+    def all_gather(self):
+        if self.world == 1:
+            self.gathered.copy_(self.partial)
+        else:
+            self.dist.all_gather_into_tensor(self.gathered, self.partial, group=self.group)
+        return self.gathered
+
+
+class ShardedMarch:
+    """Drives one rank's HeatBatch through the split-phase sub-timestep with the zone exchange."""
+
+    def __init__(self, md_shard, rank, n_ranks, device_index=0, **batch_opts):
+        import torch
+        from .binding import HeatBatch
+        self.torch = torch
+        torch.cuda.set_device(device_index)
+        # A dedicated non-default stream: the library runs its kernels on it and torch orders the
+        # collective against it (the legacy default stream has handle 0, which the C ABI reads as
+        # "create your own stream").
+        self.stream = torch.cuda.Stream(device=device_index)
+        self.batch = HeatBatch(md_shard, device=device_index, stream=self.stream.cuda_stream, n_ranks=n_ranks,
+                               rank=rank, **batch_opts)
+        self.exchange = ZoneExchange(int(md_shard["n_zones"]), torch.device("cuda", device_index))
+        self.batch.use_partials(self.exchange.partial.data_ptr())
+        self.n_ranks = n_ranks
+
+    def march_resident(self, weather, zone_a0=None, zone_b0=None):
+        """≙ ThermalModel::march on the device-resident state of this shard (asynchronous)."""
+        b = self.batch
+        with self.torch.cuda.stream(self.stream):
+            b.set_weather(weather, zone_a0, zone_b0)
+            for i in range(len(weather)):
+                b.step_surfaces(i)
+                g = self.exchange.all_gather()
+                b.step_zones(g.data_ptr(), self.exchange.world)
+
+    def synchronize(self):
+        self.batch.synchronize()
+
+    def close(self):
+        self.batch.close()

@@ -182,6 +182,9 @@ int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n
 int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step);
 int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks);
 double *heat_batch_zone_partials(heat_batch *b); /* device pointer, [2][n_zones] doubles */
+/* Makes step_surfaces write the partial sums into caller-owned device memory ([2][n_zones] doubles,
+ * e.g. a tensor the caller hands to its collective); NULL restores the batch's own buffer. */
+int heat_batch_use_partials(heat_batch *b, double *partials_dev);
 
 /* Introspection (tests, bench). */
 int64_t heat_batch_n_surfaces(const heat_batch *b);

@@ -173,3 +173,24 @@ def test_error_codes(oracle):
         with pytest.raises(HeatError) as e:
             b.march(st, np.array([[10., 0., 1.]]))
         assert e.value.code > 0  # numerical failure, like the reference's panic
+
+
+@pytest.mark.parametrize("case", ["massive_no_ir_no_solar", "mixed_no_ir_no_solar", "nomass_no_ir_no_solar", "massive_full"])
+def test_config1_energyplus_series_through_the_abi(oracle, case):
+    """BASELINE config 1 (and its mixed / no-mass / full-radiation siblings): the reference's validation
+    harness (validate_wall_heat_transfer.rs:615-711) driven through heat_batch_march, step by step with
+    the caller-owned state, against the same harness on the oracle."""
+    import os
+    from test_energyplus_series import CASES, GOLD, march_series, single_zone_model
+    layers, emis, sol = CASES[case]
+    fx = dict(np.load(os.path.join(GOLD, "wall_%s.npz" % case)))
+    fx = {k: v[:400] for k, v in fx.items()}
+    md, st, d, n_sub = single_zone_model(oracle, layers, emis, sol)
+    ref_state = st.copy()
+    ref = march_series(oracle, md, ref_state, n_sub, fx, emis)
+    got_state = st.copy()
+    with HeatBatch(md) as b:
+        b.upload_state(got_state)
+        got = march_series(oracle, md, got_state, n_sub, fx, emis, march=lambda s, w: b.march(s, w))
+    assert np.allclose(got, ref, rtol=RTOL, atol=ATOL)
+    assert_state_close(md, ref_state, got_state)

@@ -1,0 +1,117 @@
+"""The N > 1 path on CPU: world_size = 2, gloo.
+
+Product code under test (heat_amd/sharded.py): the shard plan, the model-dict shard, and
+ZoneExchange.all_gather with its [rank][2][n_zones] block layout. The per-rank surface work and the
+zone formula are done by the oracle / numpy here (a GPU is needed for the real kernels; the same
+sequence on the GPU is test_parity_gpu.py::test_split_phase_steps_equal_fused_march and
+test_sharded_single_gpu_nccl).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from heat_amd import modeldict as mdl
+    from heat_amd.sharded import ZoneExchange, shard_model, shard_ranges
+    from oracle import oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        md, state0 = mdl.ragged_mixed(600, Z=6, dt=45.0, seed=9)
+        # walls between neighbouring zones make zones span both ranks
+        weather = mdl.weather_series(6, 45.0)
+        a0 = np.linspace(0., 100., 6)
+        b0 = np.linspace(0., 5., 6)
+        Z = 6
+
+        ref = state0.copy()
+        rc, _ = orc.OracleModel(md).march(ref, weather, a0, b0)
+        assert rc == 0
+
+        shard = shard_model(md, rank, world)
+        bounds = shard_ranges(md["n_surfaces"], world)
+        assert shard["n_surfaces"] == bounds[rank + 1] - bounds[rank]
+        om = orc.OracleModel(shard)
+        ex = ZoneExchange(Z, torch.device("cpu"))
+        assert ex.world == world
+        state = state0.copy()
+        for i in range(len(weather)):
+            t_cur = state[md["zone_slot"]].copy()
+            rc, _ = om.iterate_surfaces(state, weather[i, 1], weather[i, 2], weather[i, 0])
+            assert rc == 0
+            a, b, c = om.zones_abc(state)          # this rank's partial sums (+ c from the zone state)
+            ex.partial[:Z] = torch.from_numpy(a)
+            ex.partial[Z:] = torch.from_numpy(b)
+            g = ex.all_gather().numpy().reshape(world, 2, Z)
+            at, bt = a0.copy(), b0.copy()
+            for r in range(world):                  # rank-ordered sum, as k_zone_update does
+                at += g[r, 0]
+                bt += g[r, 1]
+            ft = np.where(np.abs(bt) > 1e-9, at / bt + (t_cur - at / bt) * np.exp(-bt * md["dt"] / c), t_cur)
+            state[md["zone_slot"]] = ft
+        # every rank holds identical zone temperatures, equal to the single-process result
+        zt = torch.from_numpy(state[md["zone_slot"]].copy())
+        both = torch.zeros(world * Z, dtype=torch.float64)
+        dist.all_gather_into_tensor(both, zt)
+        both = both.numpy().reshape(world, Z)
+        assert np.array_equal(both[0], both[1])
+        assert np.allclose(both[0], ref[md["zone_slot"]], rtol=1e-9, atol=1e-9)
+        # this rank's surfaces match the single-process march
+        ns = mdl.node_slots(shard)
+        assert np.allclose(state[ns], ref[ns], rtol=1e-9, atol=1e-9)
+        for k in ("hs_front_slot", "hs_back_slot", "flow_front_slot", "flow_back_slot"):
+            assert np.allclose(state[shard[k]], ref[shard[k]], rtol=1e-9, atol=1e-9)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_zone_exchange_matches_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_shard_ranges_and_subset():
+    sys.path.insert(0, ROOT)
+    from heat_amd import modeldict as mdl
+    from heat_amd.sharded import shard_model, shard_ranges
+    b = shard_ranges(10, 4)
+    assert list(b) == [0, 3, 6, 8, 10]
+    md, st = mdl.ragged_mixed(50, Z=2, dt=45.0, seed=2)
+    parts = [shard_model(md, r, 3) for r in range(3)]
+    assert sum(p["n_surfaces"] for p in parts) == 50
+    assert np.array_equal(np.concatenate([mdl.node_slots(p) for p in parts]), mdl.node_slots(md))
+    assert np.array_equal(np.concatenate([p["mass"] for p in parts]), md["mass"])
+    assert all(p["n_state"] == md["n_state"] and p["n_zones"] == 2 for p in parts)
