@@ -50,6 +50,12 @@ class ShardedMarch:
     """Drives one rank's HeatBatch through the split-phase sub-timestep with the zone exchange."""
 
     def __init__(self, md_shard, rank, n_ranks, device_index=0, **batch_opts):
+        import sys
+        from . import binding
+        if binding._lib is not None and "torch" not in sys.modules:
+            raise RuntimeError(
+                "heat_amd: libheat_amd.so was loaded before torch; torch ships its own HIP runtime and the two "
+                "cannot share a device in one process. Import torch before creating the first HeatBatch.")
         import torch
         from .binding import HeatBatch
         self.torch = torch

@@ -194,3 +194,17 @@ def test_config1_energyplus_series_through_the_abi(oracle, case):
         got = march_series(oracle, md, got_state, n_sub, fx, emis, march=lambda s, w: b.march(s, w))
     assert np.allclose(got, ref, rtol=RTOL, atol=ATOL)
     assert_state_close(md, ref_state, got_state)
+
+
+def test_sharded_march_single_rank_nccl():
+    """The multi-GPU driver (heat_amd/sharded.py) with world_size = 1 over RCCL: the same split-phase
+    sequence and exchange the N-GPU bench runs, checked against the oracle. Runs in a fresh process
+    because torch must be imported before the HIP library is loaded (two HIP runtimes in one process
+    otherwise: torch ships its own libamdhip64)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "sharded_nccl_worker.py")], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "SHARDED OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
