@@ -72,7 +72,10 @@ struct DevBuf {
 
 constexpr int kMaxNodesGeneral = 4096;
 constexpr int kScratchArrays = 7;
-const int kFastM[3] = {4, 8, 16};
+constexpr int kNumFast = 6;                       // fast classes: (M, no-mass facings allowed)
+const int kFastM[kNumFast] = {4, 4, 8, 8, 16, 16};
+const int kFastNM[kNumFast] = {0, 1, 0, 1, 0, 1};
+constexpr int kGeneral = kNumFast;
 
 }  // namespace
 
@@ -89,8 +92,8 @@ struct heat_batch {
     int64_t class_counts[4] = {0, 0, 0, 0};
 
     // layout
-    int n_fast_tiles[3] = {0, 0, 0};
-    DevBuf<FastTile> d_fast_tiles[3];
+    int n_fast_tiles[kNumFast] = {0, 0, 0, 0, 0, 0};
+    DevBuf<FastTile> d_fast_tiles[kNumFast];
     int n_gen_tiles = 0;
     DevBuf<GeneralTile> d_gen_tiles;
     int64_t gen_base = 0;     // first node slot of the general group
@@ -100,12 +103,11 @@ struct heat_batch {
     DevBuf<int32_t> d_cav_idx;
     DevBuf<CavityDev> d_cavs;
 
-    DevBuf<int32_t> d_meta, d_front_zone, d_back_zone;
-    DevBuf<double> d_front_amb, d_back_amb, d_front_emis, d_back_emis, d_area, d_perimeter, d_cos_tilt,
-        d_nx, d_ny, d_wind_mod, d_alpha_f0, d_alpha_bn, d_hs_fix_f, d_hs_fix_b;
-    DevBuf<double> d_solar_f, d_solar_b, d_ir_f, d_ir_b;
-    DevBuf<double> d_hs;    // [hs_f | hs_b]
-    DevBuf<double> d_flow;  // [flow_f | flow_b]
+    DevBuf<int32_t> d_meta;        // node count per device surface (upload/download kernels)
+    DevBuf<SideConst> d_side_const;  // [2 * S]: front records, then back records
+    DevBuf<SideDyn> d_side_dyn;      // [2 * S]
+    DevBuf<SideOut> d_side_out;      // [2 * S]
+    DevBuf<double> d_hs_fix;         // [2 * S] or empty
     DevBuf<int64_t> d_first_slot, d_slots;  // d_slots: 8 arrays of n_surf
     DevBuf<int64_t> d_zone_slot, d_zone_off;
     DevBuf<ZoneEntry> d_zone_entries;
@@ -125,7 +127,7 @@ struct heat_batch {
     std::vector<int64_t> h_first_slot, h_node_count, h_out_slots[4], h_zone_slot_h;
     std::vector<double> h_stage;
 
-    SurfArrays sa{};
+    SideArrays sa{};
     NodeArrays na{};
     SlotArrays sl{};
 
@@ -153,21 +155,28 @@ namespace {
 struct Placed {
     int64_t s;   // original surface index
     int n;       // node count
-    int cls;     // 0..2 fast (M = 4, 8, 16), 3 general
+    int cls;     // 0..kNumFast-1 fast classes, kGeneral = catch-all
     int k;       // lanes per surface (fast)
 };
 
-// Decides whether a surface can take the register-resident fast path.
+// Decides whether a surface can take the register-resident fast path:
+// solid conductances only, solar absorbed at the two faces only, every interior node massive; the
+// face nodes may be no-mass facings (each then is an isolated one-node no-mass chunk).
 int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
-    if (opt.force_general) return 3;
+    if (opt.force_general) return kGeneral;
+    if (n < 2) return kGeneral;
     const int64_t o = d->node_offset[s];
+    int nm = 0;
     for (int i = 0; i < n; i++) {
-        if (d->mass[o + i] < kMassThreshold) return 3;                        // no-mass node
-        if (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0) return 3;  // gas cavity
-        if (i > 0 && d->front_alpha[o + i] != 0.0) return 3;                  // solar absorbed inside
-        if (i < n - 1 && d->back_alpha[o + i] != 0.0) return 3;
+        if (d->mass[o + i] < kMassThreshold) {
+            if (i != 0 && i != n - 1) return kGeneral;                        // no-mass node inside
+            nm = 1;
+        }
+        if (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0) return kGeneral;  // gas cavity
+        if (i > 0 && d->front_alpha[o + i] != 0.0) return kGeneral;           // solar absorbed inside
+        if (i < n - 1 && d->back_alpha[o + i] != 0.0) return kGeneral;
     }
-    if (n < 2) return 3;
+    if (n == 2 && d->mass[o] < kMassThreshold && d->mass[o + 1] < kMassThreshold) return kGeneral;  // 2-node chunk
     int M = opt.nodes_per_lane;
     if (M == 0) {
         // Same padding (to a multiple of 4) either way; M = 8 halves the per-surface boundary work.
@@ -176,8 +185,8 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
         M = (n4 % 8 == 0) ? 8 : 4;
     }
     const int k = (n + M - 1) / M;
-    if (k > kWave) return 3;
-    return M == 4 ? 0 : (M == 8 ? 1 : 2);
+    if (k > kWave) return kGeneral;
+    return (M == 4 ? 0 : (M == 8 ? 2 : 4)) + nm;
 }
 
 int check_desc(const heat_batch_desc *d) {
@@ -263,21 +272,21 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     for (int64_t s = 0; s < S; s++) {
         const int n = (int)(d->node_offset[s + 1] - d->node_offset[s]);
         const int cls = classify(d, s, n, opt);
-        const int M = cls < 3 ? kFastM[cls] : 0;
-        placed[s] = Placed{s, n, cls, cls < 3 ? (n + M - 1) / M : 1};
-        b->class_counts[cls]++;
+        const int M = cls < kGeneral ? kFastM[cls] : 0;
+        placed[s] = Placed{s, n, cls, cls < kGeneral ? (n + M - 1) / M : 1};
+        b->class_counts[cls < kGeneral ? cls / 2 : 3]++;
     }
     std::vector<int64_t> order(S);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
         const Placed &a = placed[x], &c = placed[y];
         if (a.cls != c.cls) return a.cls < c.cls;
-        if (a.cls < 3) return a.k < c.k;
+        if (a.cls < kGeneral) return a.k < c.k;
         return a.n < c.n;
     });
 
     // ---- tiles ----
-    std::vector<FastTile> fast_tiles[3];
+    std::vector<FastTile> fast_tiles[kNumFast];
     std::vector<GeneralTile> gen_tiles;
     std::vector<int64_t> dev_of(S);            // original -> device surface
     std::vector<int64_t> node0_index(S), nodeN_index(S);  // index of first / last node in the T buffer
@@ -289,7 +298,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     std::vector<NodeMap> nmap(S);
     while (pos < (size_t)S) {
         const Placed &p0 = placed[order[pos]];
-        if (p0.cls < 3) {
+        if (p0.cls < kGeneral) {
             const int M = kFastM[p0.cls], k = p0.k;
             const int Gmax = kWave / k, Lk = Gmax * k;
             size_t end = pos;
@@ -356,7 +365,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         const int64_t s = orig_of[dd];
         const int64_t o = d->node_offset[s];
         const int n = placed[s].n;
-        const bool gen = placed[s].cls == 3;
+        const bool gen = placed[s].cls == kGeneral;
         for (int i = 0; i < n; i++) {
             const int64_t idx = node_index(dd, i);
             const double mass = d->mass[o + i];
@@ -375,28 +384,40 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         nodeN_index[s] = node_index(dd, n - 1);
     }
 
-    // ---- per-surface constants (device order) ----
-    std::vector<int32_t> hMeta(S), hFz(S), hBz(S);
-    std::vector<double> hFamb(S), hBamb(S), hFe(S), hBe(S), hArea(S), hPer(S), hCos(S), hNx(S), hNy(S), hWm(S),
-        hAf0(S), hAbn(S), hFixF, hFixB;
+    // ---- per-side records (device order) ----
+    std::vector<int32_t> hMeta(S);
+    std::vector<SideConst> hSide(2 * S);
+    std::vector<double> hFix;
     std::vector<int64_t> hFirst(S), hSlots(8 * S);
     const bool has_fix = d->front_hs_fix != nullptr;
-    if (has_fix) { hFixF.resize(S); hFixB.resize(S); }
+    if (has_fix) hFix.resize(2 * S);
     for (int64_t dd = 0; dd < S; dd++) {
         const int64_t s = orig_of[dd];
         const int64_t o = d->node_offset[s];
         const int n = placed[s].n;
-        hMeta[dd] = n | (d->front_kind[s] << 16) | (d->back_kind[s] << 18);
-        hFz[dd] = d->front_kind[s] == HEAT_BOUNDARY_SPACE ? d->front_zone[s] : 0;
-        hBz[dd] = d->back_kind[s] == HEAT_BOUNDARY_SPACE ? d->back_zone[s] : 0;
-        hFamb[dd] = d->front_ambient[s]; hBamb[dd] = d->back_ambient[s];
-        hFe[dd] = d->front_emissivity[s]; hBe[dd] = d->back_emissivity[s];
-        hArea[dd] = d->area[s]; hPer[dd] = d->perimeter[s];
-        hCos[dd] = d->cos_tilt[s]; hNx[dd] = d->normal_x[s]; hNy[dd] = d->normal_y[s];
-        hWm[dd] = d->wind_modifier[s];
-        hAf0[dd] = d->front_alpha[o];
-        hAbn[dd] = d->back_alpha[o + n - 1];
-        if (has_fix) { hFixF[dd] = d->front_hs_fix[s]; hFixB[dd] = d->back_hs_fix[s]; }
+        hMeta[dd] = n;
+        const double cos_tilt = d->cos_tilt[s];
+        // is_windward: only tilted surfaces test the wind direction (surface.rs:38)
+        const int always_windward = (std::fabs(cos_tilt) < 0.98) ? 0 : 4;
+        // forced convection: 2.537 * Wf * Rf * sqrt(P * V_z / A), Rf = COEFFICIENTS[1] = 1.67, V_z = wind * modifier
+        // (convection.rs:151-168; surface.rs:646,691). Wf and sqrt(wind) are applied per sub-timestep.
+        const double forced = 2.537 * 1.67 * std::sqrt(d->perimeter[s] * d->wind_modifier[s] / d->area[s]);
+        for (int side = 0; side < 2; side++) {
+            SideConst c;
+            const int kind = side ? d->back_kind[s] : d->front_kind[s];
+            c.kind_n = kind | always_windward | (n << 16);
+            c.zone = kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : 0;
+            c.ambient = side ? d->back_ambient[s] : d->front_ambient[s];
+            c.emis = side ? d->back_emissivity[s] : d->front_emissivity[s];
+            c.alpha = side ? d->back_alpha[o + n - 1] : d->front_alpha[o];
+            // front Outdoor flips the sign (surface.rs:652); back Outdoor does not (surface.rs:689-696)
+            c.cos_eff = (side == 0 && kind == HEAT_BOUNDARY_OUTDOOR) ? -cos_tilt : cos_tilt;
+            c.forced = kind == HEAT_BOUNDARY_OUTDOOR ? forced : 0.0;
+            c.nx = d->normal_x[s];
+            c.ny = d->normal_y[s];
+            hSide[(int64_t)side * S + dd] = c;
+            if (has_fix) hFix[(int64_t)side * S + dd] = side ? d->back_hs_fix[s] : d->front_hs_fix[s];
+        }
         hFirst[dd] = d->first_node_slot[s];
         const int64_t *src[8] = {d->hs_front_slot, d->hs_back_slot, d->flow_front_slot, d->flow_back_slot,
                                  d->solar_front_slot, d->solar_back_slot, d->ir_front_slot, d->ir_back_slot};
@@ -436,7 +457,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     if (Z > 0) b->h_zone_slot_h.assign(d->zone_slot, d->zone_slot + Z);
 
     // ---- upload ----
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < kNumFast; c++) {
         b->n_fast_tiles[c] = (int)fast_tiles[c].size();
         HIP_TRY(b->d_fast_tiles[c].upload(fast_tiles[c]));
     }
@@ -460,30 +481,10 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         HIP_TRY(b->d_cavs.upload(hc));
     }
     HIP_TRY(b->d_meta.upload(hMeta));
-    HIP_TRY(b->d_front_zone.upload(hFz));
-    HIP_TRY(b->d_back_zone.upload(hBz));
-    HIP_TRY(b->d_front_amb.upload(hFamb));
-    HIP_TRY(b->d_back_amb.upload(hBamb));
-    HIP_TRY(b->d_front_emis.upload(hFe));
-    HIP_TRY(b->d_back_emis.upload(hBe));
-    HIP_TRY(b->d_area.upload(hArea));
-    HIP_TRY(b->d_perimeter.upload(hPer));
-    HIP_TRY(b->d_cos_tilt.upload(hCos));
-    HIP_TRY(b->d_nx.upload(hNx));
-    HIP_TRY(b->d_ny.upload(hNy));
-    HIP_TRY(b->d_wind_mod.upload(hWm));
-    HIP_TRY(b->d_alpha_f0.upload(hAf0));
-    HIP_TRY(b->d_alpha_bn.upload(hAbn));
-    if (has_fix) {
-        HIP_TRY(b->d_hs_fix_f.upload(hFixF));
-        HIP_TRY(b->d_hs_fix_b.upload(hFixB));
-    }
-    HIP_TRY(b->d_solar_f.zeros(S));
-    HIP_TRY(b->d_solar_b.zeros(S));
-    HIP_TRY(b->d_ir_f.zeros(S));
-    HIP_TRY(b->d_ir_b.zeros(S));
-    HIP_TRY(b->d_hs.zeros(2 * S));
-    HIP_TRY(b->d_flow.zeros(2 * S));
+    HIP_TRY(b->d_side_const.upload(hSide));
+    if (has_fix) HIP_TRY(b->d_hs_fix.upload(hFix));
+    HIP_TRY(b->d_side_dyn.zeros(2 * S));
+    HIP_TRY(b->d_side_out.zeros(2 * S));
     HIP_TRY(b->d_first_slot.upload(hFirst));
     HIP_TRY(b->d_slots.upload(hSlots));
     {
@@ -507,18 +508,13 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
 
     // ---- argument bundles ----
-    SurfArrays &sa = b->sa;
-    sa.meta = b->d_meta.p; sa.front_zone = b->d_front_zone.p; sa.back_zone = b->d_back_zone.p;
-    sa.front_ambient = b->d_front_amb.p; sa.back_ambient = b->d_back_amb.p;
-    sa.front_emis = b->d_front_emis.p; sa.back_emis = b->d_back_emis.p;
-    sa.area = b->d_area.p; sa.perimeter = b->d_perimeter.p;
-    sa.cos_tilt = b->d_cos_tilt.p; sa.normal_x = b->d_nx.p; sa.normal_y = b->d_ny.p; sa.wind_mod = b->d_wind_mod.p;
-    sa.alpha_f0 = b->d_alpha_f0.p; sa.alpha_bn = b->d_alpha_bn.p;
-    sa.hs_fix_f = has_fix ? b->d_hs_fix_f.p : nullptr;
-    sa.hs_fix_b = has_fix ? b->d_hs_fix_b.p : nullptr;
-    sa.solar_f = b->d_solar_f.p; sa.solar_b = b->d_solar_b.p; sa.ir_f = b->d_ir_f.p; sa.ir_b = b->d_ir_b.p;
-    sa.hs_f = b->d_hs.p; sa.hs_b = b->d_hs.p + S;
-    sa.flow_f = b->d_flow.p; sa.flow_b = b->d_flow.p + S;
+    SideArrays &sa = b->sa;
+    sa.sc = b->d_side_const.p;
+    sa.dyn = b->d_side_dyn.p;
+    sa.out = b->d_side_out.p;
+    sa.hs_fix = has_fix ? b->d_hs_fix.p : nullptr;
+    sa.S = (int32_t)S;
+    sa.pad = 0;
     NodeArrays &na = b->na;
     na.T = b->d_T.p; na.V = b->d_V.p; na.U = b->d_U.p;
     na.alpha_f = b->d_alpha_f.p; na.alpha_b = b->d_alpha_b.p; na.cav = b->d_cav_idx.p; na.mass = b->d_mass.p;
@@ -536,16 +532,17 @@ int select_device(heat_batch *b) {
 
 // iterate_surfaces for every group (model.rs:388-408)
 void enqueue_surfaces(heat_batch *b, int step_fixed) {
-    for (int c = 0; c < 3; c++)
-        launch_surfaces_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa, b->d_weather.p,
-                             b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p, b->stream);
+    for (int c = 0; c < kNumFast; c++)
+        launch_surfaces_fast(kFastM[c], kFastNM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa,
+                             b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
+                             b->d_nomass_iters.p, b->stream);
     launch_surfaces_general(b->d_gen_tiles.p, b->n_gen_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
                             b->d_scratch.p, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
                             b->d_nomass_iters.p, b->stream);
 }
 
 void enqueue_zones(heat_batch *b, int mode) {
-    launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_hs.p, b->d_zone_a0.p, b->d_zone_b0.p,
+    launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_side_out.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
                  b->d_flags.p, mode, b->stream);
 }
@@ -646,14 +643,14 @@ static int transfer_in(heat_batch *b, const double *state, size_t n_state, bool 
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy(b->d_state.p, state, n_state * sizeof(double), hipMemcpyHostToDevice));
     if (full) {
-        for (int c = 0; c < 3; c++)
+        for (int c = 0; c < kNumFast; c++)
             launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
                               b->d_first_slot.p, b->d_state.p, 0, b->stream);
         launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p,
                              b->d_state.p, 0, b->stream);
     }
-    launch_surf_scalars((int)b->n_surf, b->sl, b->sa, b->d_solar_f.p, b->d_solar_b.p, b->d_ir_f.p, b->d_ir_b.p,
-                        b->d_state.p, 0, full ? 3 : 1, b->stream);
+    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_state.p, 0, full ? 3 : 1,
+                        b->stream);
     launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 0, b->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -672,13 +669,12 @@ int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
     if ((int64_t)n_state != b->n_state) return fail(HEAT_E_SIZE, "n_state %zu, batch was created for %lld", n_state, (long long)b->n_state);
     int rc = select_device(b);
     if (rc) return rc;
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < kNumFast; c++)
         launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
                           b->d_first_slot.p, b->d_state.p, 1, b->stream);
     launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p, b->d_state.p,
                          1, b->stream);
-    launch_surf_scalars((int)b->n_surf, b->sl, b->sa, b->d_solar_f.p, b->d_solar_b.p, b->d_ir_f.p, b->d_ir_b.p,
-                        b->d_state.p, 1, 2, b->stream);
+    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_state.p, 1, 2, b->stream);
     launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 1, b->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -715,8 +711,8 @@ int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n
     }
     for (int i = 0; i < n_sub; i++) {
         // sin/cos of the wind direction as is_windward takes them (surface.rs:40)
-        b->h_weather[i] = StepWeather{weather[i].dry_bulb, weather[i].wind_speed, std::sin(weather[i].wind_direction),
-                                      std::cos(weather[i].wind_direction)};
+        b->h_weather[i] = StepWeather{weather[i].dry_bulb, std::sqrt(weather[i].wind_speed),
+                                      std::sin(weather[i].wind_direction), std::cos(weather[i].wind_direction)};
     }
     b->n_weather = n_sub;
     if (n_sub > 0)

@@ -14,6 +14,8 @@
 // No MFMA anywhere: this is an HBM-bound f64 stencil.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
 #include "layout.hpp"
@@ -22,33 +24,47 @@ namespace heat {
 
 // ---------------------------------------------------------------------------
 // Boundary conditions of one side — reference src/surface.rs:596-717.
-//   kind      Boundary kind of this side
+//   c         the side's constants (kind, effective cos tilt, forced coefficient, normal)
 //   air_t     boundary temperature of this side (get_boundary_temperature, model.rs:79-96)
 //   rad_alt   rad_temperature for non-Outdoor kinds (t_front / t_back / quirk, surface.rs:616,631,665,676)
+//   rad_out   rad_temperature for Outdoor: (ir/sigma)^0.25 - 273.15, precomputed at upload
 //   surf_t    surface temperature the reference reads from `state` for this side
-//   cos_eff   cos_surface_tilt as the reference sets it (front Outdoor flips the sign, surface.rs:652)
-__device__ __forceinline__ void eval_side(int kind, double air_t, double rad_alt, double ir, double surf_t,
-                                          double cos_eff, double air_speed, double area, double perimeter,
-                                          bool windward, bool need_rad, double &hs, double &rad_t, int &bad) {
-    const double natural = tarp_natural(air_t, surf_t, cos_eff, bad);
-    if (kind == KIND_OUTDOOR) {
-        hs = tarp_forced(air_speed, area, perimeter, windward) + natural;
-        rad_t = need_rad ? ir_to_rad_temperature(ir) : 0.0;
+__device__ __forceinline__ void eval_side(const SideConst &c, const StepWeather &w, double air_t, double rad_alt,
+                                          double rad_out, double surf_t, double &hs, double &rad_t, int &bad) {
+    const double natural = tarp_natural(air_t, surf_t, c.cos_eff, bad);
+    if ((c.kind_n & 3) == KIND_OUTDOOR) {
+        // is_windward, surface.rs:37-46
+        const bool windward = (c.kind_n & 4) ? true : ((c.nx * w.sin_wd + c.ny * w.cos_wd) > 0.0);
+        const double wf = windward ? 1.0 : 0.5;
+        hs = wf * (c.forced * w.sqrt_ws) + natural;  // convection.rs:161-167
+        rad_t = rad_out;
     } else {
         hs = natural;
         rad_t = rad_alt;
     }
 }
 
+__device__ __forceinline__ double boundary_temperature(const SideConst &c, const StepWeather &w,
+                                                       const double *__restrict__ zone_T) {
+    const int kind = c.kind_n & 3;  // get_boundary_temperature, model.rs:79-96
+    if (kind == KIND_SPACE) return zone_T[c.zone];
+    if (kind == KIND_AMBIENT) return c.ambient;
+    return w.t_out;
+}
+
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
 
 // ---------------------------------------------------------------------------
 // Fast path. One wavefront per tile; see layout.hpp for the lane blocking.
-template <int M>
+// NM = 1: the surface may carry a no-mass FACING node (node 0 and/or node n-1, every other node
+// massive): each is a one-node no-mass chunk, solved by the reference's damped fixed-point loop
+// (march_nomass, surface.rs:790-898) in the face lane before the massive nodes march.
+template <int M, int NM, int VAR = 0>
 __global__ void __launch_bounds__(256)
-k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SurfArrays sa,
+k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
-                const double *__restrict__ zone_T, int *__restrict__ flags) {
+                const double *__restrict__ zone_T, int *__restrict__ flags,
+                unsigned long long *__restrict__ nomass_iters) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave >= n_tiles) return;
@@ -81,33 +97,33 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
         }
     }
+    if constexpr (VAR == 3) {  // ablation build: stream T, V, U through and nothing else
+        if (active) {
+            double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
+#pragma unroll
+            for (int jp = 0; jp < M / 2; jp++)
+                pT[jp * Lk + lane] = make_double2(T[2 * jp] + 1e-9 * V[2 * jp] * U[2 * jp],
+                                                  T[2 * jp + 1] + 1e-9 * V[2 * jp + 1] * U[2 * jp + 1]);
+        }
+        return;
+    }
 
-    // ---- per-surface scalars (every lane of a surface reads the same address) ----
-    const int meta = sa.meta[d];
-    const int nn = meta & 0xffff;
-    const int fk = (meta >> 16) & 3;
-    const int bk = (meta >> 18) & 3;
     const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
     const StepWeather w = weather[step];
-    const double cos_tilt = sa.cos_tilt[d];
-    const double area = sa.area[d];
-    const double perimeter = sa.perimeter[d];
-    const double air_speed = w.wind_speed * sa.wind_mod[d];
-    const bool windward = is_windward(w.sin_wd, w.cos_wd, cos_tilt, sa.normal_x[d], sa.normal_y[d]);
-
-    double t_front_b, t_back_b;  // get_boundary_temperature, model.rs:79-96
-    if (fk == KIND_SPACE) t_front_b = zone_T[sa.front_zone[d]];
-    else if (fk == KIND_AMBIENT) t_front_b = sa.front_ambient[d];
-    else t_front_b = w.t_out;
-    if (bk == KIND_SPACE) t_back_b = zone_T[sa.back_zone[d]];
-    else if (bk == KIND_AMBIENT) t_back_b = sa.back_ambient[d];
-    else t_back_b = w.t_out;
-
+    const int S = sd.S;
     const bool is_first = (seg == 0);
     const bool is_last = (seg == k - 1);
-    const int jl = nn - 1 - (k - 1) * M;  // local index of the last node inside the last lane
     const int first_lane = g * k;
     const int last_lane = min(g * k + k - 1, kWave - 1);
+
+    // The first lane of a surface owns the front side, every other lane loads the back side
+    // (only the last lane's value is used). Tiles with k == 1 own both sides (second record below).
+    const bool my_back = !is_first;
+    const int sidx = (my_back ? S : 0) + d;
+    const SideConst c = sd.sc[sidx];
+    const SideDyn dy = sd.dyn[sidx];
+    const int nn = c.kind_n >> 16;
+    const int jl = nn - 1 - (k - 1) * M;  // local index of the last node inside the last lane
 
     auto pick_last = [&](const double (&x)[M]) {
         double r = x[0];
@@ -116,31 +132,38 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         return r;
     };
 
+    int bad = 0;
+    // One evaluation of calc_border_conditions for the side described by `cc` (surface.rs:596-717).
+    // Returns hs; air_t / rad_t / surf_t are what get_k_q and rad_hs need afterwards.
+    auto side = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, double T0v, double Tnv,
+                    double &air_t, double &rad_t, double &surf_t) {
+        air_t = boundary_temperature(cc, w, zone_T);
+        double rad_alt = air_t;
+        surf_t = back ? Tnv : T0v;
+        if (back && (cc.kind_n & 3) == KIND_AMBIENT) {
+            // back/Ambient takes t_front and the FRONT surface temperature (surface.rs:672-686)
+            const SideConst fc = sd.sc[rec - S];
+            rad_alt = boundary_temperature(fc, w, zone_T);
+            surf_t = T0v;
+        }
+        double hs;
+        if constexpr (VAR >= 1) {  // ablation build: no boundary physics
+            hs = 5.0 + 1e-3 * surf_t;
+            rad_t = rad_alt;
+        } else {
+            eval_side(cc, w, air_t, rad_alt, dd.rad_t, surf_t, hs, rad_t, bad);
+        }
+        if (hs != hs) bad |= FLAG_NAN_HS;  // surface.rs:704-707
+        if (sd.hs_fix != nullptr) {        // debug overrides, surface.rs:708-714
+            const double fix = sd.hs_fix[rec];
+            if (fix == fix) hs = fix;
+        }
+        return hs;
+    };
+
     // Surface temperatures as the reference reads them from `state` (pre-step).
     const double T0 = shfl_f64(T[0], first_lane);
     const double Tn = shfl_f64(pick_last(T), last_lane);
-
-    int bad = 0;
-    // Which side this lane evaluates: the first lane the front, every other lane the back
-    // (only the last lane's value is used). Tiles with k == 1 evaluate both, one after the other.
-    auto side = [&](bool back, double T0v, double Tnv, bool need_rad, double &hs, double &rad_t) {
-        const int kind = back ? bk : fk;
-        const double air_t = back ? t_back_b : t_front_b;
-        // back/Ambient uses t_front and the FRONT temperature (surface.rs:672-686)
-        const bool quirk = back && (bk == KIND_AMBIENT);
-        const double rad_alt = (back && !quirk) ? t_back_b : t_front_b;
-        const double surf_t = (back && !quirk) ? Tnv : T0v;
-        const double cos_eff = (!back && fk == KIND_OUTDOOR) ? -cos_tilt : cos_tilt;
-        const double ir = need_rad ? (back ? sa.ir_b[d] : sa.ir_f[d]) : 0.0;
-        eval_side(kind, air_t, rad_alt, ir, surf_t, cos_eff, air_speed, area, perimeter, windward, need_rad,
-                  hs, rad_t, bad);
-        if (hs != hs) bad |= FLAG_NAN_HS;  // surface.rs:704-707
-        if (sa.hs_fix_f != nullptr) {      // debug overrides, surface.rs:708-714
-            const double fix = back ? sa.hs_fix_b[d] : sa.hs_fix_f[d];
-            if (fix == fix) hs = fix;
-        }
-        return surf_t;
-    };
 
     // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769),
     // already multiplied by V = dt/C as rearrange_k does (surface.rs:168-187).
@@ -148,46 +171,96 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 #pragma unroll
     for (int j = 0; j < M; j++) { GV[j] = 0.0; QP[j] = 0.0; }
 
-    auto add_front = [&](double hs, double rad_t, double surf_t) {
-        const double rhs = rad_hs(sa.front_emis[d], rad_t, surf_t);
-        double sol = sa.solar_f[d];
-        if (sol != sol || sol < 0.0) sol = 0.0;
-        const double q = (t_front_b * hs + rhs * (rad_t - T[0])) + sa.alpha_f0[d] * sol;
-        GV[0] += V[0] * hs;
-        QP[0] += V[0] * q;
-    };
-    auto add_back = [&](double hs, double rad_t, double surf_t) {
-        const double rhs = rad_hs(sa.back_emis[d], rad_t, surf_t);
-        double sol = sa.solar_b[d];
-        if (sol != sol) sol = 0.0;  // sic: only NaN is clamped (surface.rs:920-923)
-        const double tl = pick_last(T);
-        const double q = (t_back_b * hs + rhs * (rad_t - tl)) + sa.alpha_bn[d] * sol;
+    // Conductance towards the previous lane's last node, and that node's temperature.
+    double UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
+    if (is_first) UL = 0.0;
+    unsigned int nm_passes = 0;
+    // Last node of the previous lane (wave-wide exchange: must not sit inside a divergent branch).
+    double T_prev_last = 0.0;
+    if constexpr (NM) T_prev_last = shfl_f64(T[M - 1], (lane + kWave - 1) & (kWave - 1));
+
+    auto add_face = [&](const SideConst &cc, const SideDyn &dd, bool back, double hs, double air_t, double rad_t,
+                        double surf_t) {
+        const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
+        const double sol = cc.alpha * dd.solar;
+        if constexpr (NM) {
+            // One-node no-mass chunk at this face (discretization.rs:658-697 for nnodes == 1):
+            //   K = (0 - h_face) - u_inner,  q = (q_face + u_inner * T_inner) + solar,  x = -q / K,
+            //   T <- (T + x) / 2 until the error stops shrinking or err < tol (surface.rs:836-895).
+            const double vface = back ? pick_last(V) : V[0];
+            if (active && vface == 0.0 && nn >= 2) {
+                double u_in, t_in;
+                if (!back) {
+                    u_in = U[0];
+                    t_in = T[1 % M];
+                } else {
+                    // inner neighbour of the last node: previous node of this lane, or of the previous lane
+                    double up = UL, tp = T_prev_last;
 #pragma unroll
-        for (int j = 0; j < M; j++) {
-            if (j == jl) {
-                GV[j] += V[j] * hs;
-                QP[j] += V[j] * q;
+                    for (int j = 1; j < M; j++) {
+                        up = (j == jl) ? U[j - 1] : up;
+                        tp = (j == jl) ? T[j - 1] : tp;
+                    }
+                    u_in = up;
+                    t_in = tp;
+                }
+                double Tc = back ? pick_last(T) : T[0];
+                const double dg = (0.0 - hs) - u_in;
+                const double nb = u_in * t_in;
+                double old_err = 99999.;
+                int count = 0;
+                for (;;) {
+                    const double qf = air_t * hs + rhs * (rad_t - Tc);
+                    const double q = ((back ? (nb + qf) : (qf + nb)) + sol) * -1.;
+                    const double x = q / dg;
+                    const double err = fabs(x - Tc);
+                    nm_passes++;
+                    if (err > old_err) break;                            // surface.rs:842-848
+                    if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
+                    Tc = (Tc + x) * 0.5;
+                    const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
+                    if (err < tol) break;
+                    old_err = err;
+                    count++;
+                }
+                if (!back) {
+                    T[0] = Tc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < M; j++) T[j] = (j == jl) ? Tc : T[j];
+                }
+                return;  // V == 0: the node takes no part in the RK4 below
+            }
+        }
+        if (!back) {
+            const double q = (air_t * hs + rhs * (rad_t - T[0])) + sol;
+            GV[0] += V[0] * hs;
+            QP[0] += V[0] * q;
+        } else {
+            const double q = (air_t * hs + rhs * (rad_t - pick_last(T))) + sol;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                GV[j] += (j == jl) ? V[j] * hs : 0.0;
+                QP[j] += (j == jl) ? V[j] * q : 0.0;
             }
         }
     };
 
-    if (k == 1) {
-        double hs, rad_t, surf_t;
-        surf_t = side(false, T0, Tn, true, hs, rad_t);
-        add_front(hs, rad_t, surf_t);
-        surf_t = side(true, T0, Tn, true, hs, rad_t);
-        add_back(hs, rad_t, surf_t);
-    } else {
-        double hs, rad_t;
-        const double surf_t = side(!is_first, T0, Tn, true, hs, rad_t);
-        if (is_first) add_front(hs, rad_t, surf_t);
-        if (is_last) add_back(hs, rad_t, surf_t);
+    double my_air, my_rad, my_surf;
+    {
+        const double hs = side(c, dy, my_back, sidx, T0, Tn, my_air, my_rad, my_surf);
+        if (is_first || is_last) add_face(c, dy, my_back, hs, my_air, my_rad, my_surf);
+    }
+    double b_air = 0.0;
+    if (k == 1) {  // single-lane surfaces: this lane is also the last one
+        const SideConst cb = sd.sc[S + d];
+        const SideDyn db = sd.dyn[S + d];
+        double b_rad, b_surf;
+        const double hs = side(cb, db, true, S + d, T0, Tn, b_air, b_rad, b_surf);
+        add_face(cb, db, true, hs, b_air, b_rad, b_surf);
     }
 
     // ---- RK4 on dT/dt = V (flux_right - flux_left - g T) + qp  (surface.rs:228-308) ----
-    // Conductance towards the previous lane's last node.
-    double UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
-    if (is_first) UL = 0.0;
 
     auto rhs_eval = [&](const double (&x)[M], double (&kk)[M]) {
         double xl = shfl_f64(x[M - 1], (lane + kWave - 1) & (kWave - 1));
@@ -206,17 +279,22 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 
     double acc[M], aux[M], kk[M];
     rhs_eval(T, kk);
+    if constexpr (VAR == 2) {  // ablation build: one Euler stage
 #pragma unroll
-    for (int j = 0; j < M; j++) { acc[j] = T[j] + kk[j] * (1.0 / 6.0); aux[j] = T[j] + 0.5 * kk[j]; }
-    rhs_eval(aux, kk);
+        for (int j = 0; j < M; j++) T[j] = T[j] + kk[j];
+    } else {
 #pragma unroll
-    for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + 0.5 * kk[j]; }
-    rhs_eval(aux, kk);
+        for (int j = 0; j < M; j++) { acc[j] = T[j] + kk[j] * (1.0 / 6.0); aux[j] = T[j] + 0.5 * kk[j]; }
+        rhs_eval(aux, kk);
 #pragma unroll
-    for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + kk[j]; }
-    rhs_eval(aux, kk);
+        for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + 0.5 * kk[j]; }
+        rhs_eval(aux, kk);
 #pragma unroll
-    for (int j = 0; j < M; j++) T[j] = acc[j] + kk[j] * (1.0 / 6.0);
+        for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + kk[j]; }
+        rhs_eval(aux, kk);
+#pragma unroll
+        for (int j = 0; j < M; j++) T[j] = acc[j] + kk[j] * (1.0 / 6.0);
+    }
 
     // ---- write back node temperatures (model.rs:145-147) ----
     if (active) {
@@ -229,20 +307,35 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const double T0n = shfl_f64(T[0], first_lane);
     const double Tln = pick_last(T);
     const double Tnn = shfl_f64(Tln, last_lane);
+    {
+        double a_, r_, s_;
+        const double hs = side(c, dy, my_back, sidx, T0n, Tnn, a_, r_, s_);
+        const double face_t = my_back ? Tln : T[0];
+        if (active && (is_first || is_last)) {
+            SideOut o;
+            o.hs = hs;
+            o.flow = (face_t - my_air) * hs;
+            sd.out[sidx] = o;
+        }
+    }
     if (k == 1) {
-        double hs, rad_t;
-        side(false, T0n, Tnn, false, hs, rad_t);
-        if (active) { sa.hs_f[d] = hs; sa.flow_f[d] = (T[0] - t_front_b) * hs; }
-        side(true, T0n, Tnn, false, hs, rad_t);
-        if (active) { sa.hs_b[d] = hs; sa.flow_b[d] = (Tln - t_back_b) * hs; }
-    } else {
-        double hs, rad_t;
-        side(!is_first, T0n, Tnn, false, hs, rad_t);
-        if (active && is_first) { sa.hs_f[d] = hs; sa.flow_f[d] = (T[0] - t_front_b) * hs; }
-        if (active && is_last) { sa.hs_b[d] = hs; sa.flow_b[d] = (Tln - t_back_b) * hs; }
-        if (!(is_first || is_last)) bad = 0;
+        const SideConst cb = sd.sc[S + d];
+        const SideDyn db = sd.dyn[S + d];
+        double a_, r_, s_;
+        const double hs = side(cb, db, true, S + d, T0n, Tnn, a_, r_, s_);
+        if (active) {
+            SideOut o;
+            o.hs = hs;
+            o.flow = (Tln - b_air) * hs;
+            sd.out[S + d] = o;
+        }
+    } else if (!(is_first || is_last)) {
+        bad = 0;
     }
     if (active && bad) atomicOr(flags, bad);
+    if constexpr (NM) {
+        if (nm_passes) atomicAdd(nomass_iters, (unsigned long long)nm_passes);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -250,7 +343,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 #pragma clang fp contract(off)
 __global__ void __launch_bounds__(256)
 k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
-                   SurfArrays sa, const CavityDev *__restrict__ cavs, double *__restrict__ scratch,
+                   SideArrays sd, const CavityDev *__restrict__ cavs, double *__restrict__ scratch,
                    const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                    const double *__restrict__ zone_T, int *__restrict__ flags,
                    unsigned long long *__restrict__ nomass_iters) {
@@ -260,11 +353,14 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
     const GeneralTile tile = tiles[wave];
     if (lane >= tile.G) return;
     const int d = tile.surf_base + lane;
+    const int S = sd.S;
 
-    const int meta = sa.meta[d];
-    const int nn = meta & 0xffff;
-    const int fk = (meta >> 16) & 3;
-    const int bk = (meta >> 18) & 3;
+    const SideConst cf = sd.sc[d];
+    const SideConst cb = sd.sc[S + d];
+    const SideDyn df = sd.dyn[d];
+    const SideDyn db = sd.dyn[S + d];
+    const int nn = cf.kind_n >> 16;
+    const int bk = cb.kind_n & 3;
     const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
     const StepWeather w = weather[step];
 
@@ -277,59 +373,43 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
     const double *Mg = na.mass + gofs;
     const int32_t *Cg = na.cav + gofs;
     const int nmax = tile.n_max;
-    double *S = scratch + tile.scratch_base + lane;                  // S(a, i) = S[(a*nmax + i)*64]
-#define SC(a, i) S[((int64_t)(a) * nmax + (i)) * kWave]
+    double *Sx = scratch + tile.scratch_base + lane;                 // SC(a, i) = Sx[(a*nmax + i)*64]
+#define SC(a, i) Sx[((int64_t)(a) * nmax + (i)) * kWave]
 #define TT(i) Tg[(int64_t)(i) * kWave]
     enum { LO = 0, DG = 1, UP = 2, QQ = 3, AUX = 4, KN = 5, ACC = 6 };
 
     int bad = 0;
-    const double cos_tilt = sa.cos_tilt[d];
-    const double area = sa.area[d];
-    const double perimeter = sa.perimeter[d];
-    const double air_speed = w.wind_speed * sa.wind_mod[d];
-    const bool windward = is_windward(w.sin_wd, w.cos_wd, cos_tilt, sa.normal_x[d], sa.normal_y[d]);
-
-    double t_front_b, t_back_b;
-    if (fk == KIND_SPACE) t_front_b = zone_T[sa.front_zone[d]];
-    else if (fk == KIND_AMBIENT) t_front_b = sa.front_ambient[d];
-    else t_front_b = w.t_out;
-    if (bk == KIND_SPACE) t_back_b = zone_T[sa.back_zone[d]];
-    else if (bk == KIND_AMBIENT) t_back_b = sa.back_ambient[d];
-    else t_back_b = w.t_out;
+    const double t_front_b = boundary_temperature(cf, w, zone_T);
+    const double t_back_b = boundary_temperature(cb, w, zone_T);
 
     // calc_border_conditions on the pre-step state (surface.rs:596-717): identical for every
     // call made before the write-back at model.rs:145-147.
     const double T0 = TT(0), Tn = TT(nn - 1);
-    const bool quirk = (bk == KIND_AMBIENT);
+    const bool quirk = (bk == KIND_AMBIENT);  // back/Ambient: t_front and the FRONT temperature (surface.rs:672-686)
     double f_hs, f_rad, b_hs, b_rad;
     const double f_surf = T0;
     const double b_surf = quirk ? T0 : Tn;
-    eval_side(fk, t_front_b, t_front_b, sa.ir_f[d], f_surf, (fk == KIND_OUTDOOR) ? -cos_tilt : cos_tilt,
-              air_speed, area, perimeter, windward, true, f_hs, f_rad, bad);
-    eval_side(bk, t_back_b, quirk ? t_front_b : t_back_b, sa.ir_b[d], b_surf, cos_tilt,
-              air_speed, area, perimeter, windward, true, b_hs, b_rad, bad);
+    eval_side(cf, w, t_front_b, t_front_b, df.rad_t, f_surf, f_hs, f_rad, bad);
+    eval_side(cb, w, t_back_b, quirk ? t_front_b : t_back_b, db.rad_t, b_surf, b_hs, b_rad, bad);
     if (f_hs != f_hs || b_hs != b_hs) bad |= FLAG_NAN_HS;
-    if (sa.hs_fix_f != nullptr) {
-        const double ff = sa.hs_fix_f[d], fb = sa.hs_fix_b[d];
+    if (sd.hs_fix != nullptr) {
+        const double ff = sd.hs_fix[d], fb = sd.hs_fix[S + d];
         if (ff == ff) f_hs = ff;
         if (fb == fb) b_hs = fb;
     }
     const double f_air = t_front_b, b_air = t_back_b;
-    const double f_radhs = rad_hs(sa.front_emis[d], f_rad, f_surf);  // surface.rs:941-948
-    const double b_radhs = rad_hs(sa.back_emis[d], b_rad, b_surf);
+    const double f_radhs = rad_hs(cf.emis, f_rad, f_surf);  // surface.rs:941-948
+    const double b_radhs = rad_hs(cb.emis, b_rad, b_surf);
 
-    double solar_front = sa.solar_f[d];
-    if (solar_front != solar_front || solar_front < 0.0) solar_front = 0.0;  // surface.rs:916-919
-    double solar_back = sa.solar_b[d];
-    if (solar_back != solar_back) solar_back = 0.0;                          // surface.rs:920-923 (sic)
+    const double solar_front = df.solar, solar_back = db.solar;  // clamped at upload (surface.rs:916-923)
     auto solar = [&](int i) {  // surface.rs:930-931
         double s = Fa[(int64_t)i * kWave] * solar_front;
         s += Ba[(int64_t)i * kWave] * solar_back;
         return s;
     };
     auto uval = [&](int gidx, double ta, double tb) {  // UValue::u_value, discretization.rs:48-55
-        const int c = Cg[(int64_t)gidx * kWave];
-        if (c >= 0) return cavity_u_value(cavs[c], ta, tb, bad);
+        const int cidx = Cg[(int64_t)gidx * kWave];
+        if (cidx >= 0) return cavity_u_value(cavs[cidx], ta, tb, bad);
         return Ug[(int64_t)gidx * kWave];
     };
     // Discretization::get_k_q (discretization.rs:596-700) into LO/DG/UP/QQ
@@ -454,20 +534,19 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
     {
         const double T0n = TT(0), Tnn = TT(nn - 1);
         double fh, bh, r_;
-        eval_side(fk, t_front_b, t_front_b, 0.0, T0n, (fk == KIND_OUTDOOR) ? -cos_tilt : cos_tilt,
-                  air_speed, area, perimeter, windward, false, fh, r_, bad);
-        eval_side(bk, t_back_b, 0.0, 0.0, quirk ? T0n : Tnn, cos_tilt,
-                  air_speed, area, perimeter, windward, false, bh, r_, bad);
+        eval_side(cf, w, t_front_b, t_front_b, df.rad_t, T0n, fh, r_, bad);
+        eval_side(cb, w, t_back_b, t_back_b, db.rad_t, quirk ? T0n : Tnn, bh, r_, bad);
         if (fh != fh || bh != bh) bad |= FLAG_NAN_HS;
-        if (sa.hs_fix_f != nullptr) {
-            const double ff = sa.hs_fix_f[d], fb = sa.hs_fix_b[d];
+        if (sd.hs_fix != nullptr) {
+            const double ff = sd.hs_fix[d], fb = sd.hs_fix[S + d];
             if (ff == ff) fh = ff;
             if (fb == fb) bh = fb;
         }
-        sa.hs_f[d] = fh;
-        sa.hs_b[d] = bh;
-        sa.flow_f[d] = (T0n - t_front_b) * fh;
-        sa.flow_b[d] = (Tnn - t_back_b) * bh;
+        SideOut of, ob;
+        of.hs = fh; of.flow = (T0n - t_front_b) * fh;
+        ob.hs = bh; ob.flow = (Tnn - t_back_b) * bh;
+        sd.out[d] = of;
+        sd.out[S + d] = ob;
     }
     if (bad) atomicOr(flags, bad);
     if (iters) atomicAdd(nomass_iters, iters);
@@ -480,7 +559,7 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
 // Zones: one wavefront per zone. mode 0: full update; mode 1: write partial (a, b) only.
 __global__ void __launch_bounds__(256)
 k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entries,
-        const double *__restrict__ T, const double *__restrict__ hs,
+        const double *__restrict__ T, const SideOut *__restrict__ out,
         const double *__restrict__ a0, const double *__restrict__ b0, const double *__restrict__ zone_vol,
         double *__restrict__ zone_T, double *__restrict__ partial, int n_zones, double dt,
         int *__restrict__ step_ptr, int *__restrict__ flags, int mode) {
@@ -492,7 +571,7 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
     const int64_t e0 = zone_off[z], e1 = zone_off[z + 1];
     for (int64_t e = e0 + lane; e < e1; e += kWave) {  // model.rs:562-585
         const ZoneEntry en = entries[e];
-        const double h = hs[en.hs_index];
+        const double h = out[en.hs_index].hs;
         const double ha = h * en.area;
         a += ha * T[en.t_index];
         b += ha;
@@ -597,30 +676,43 @@ k_nodes_general(const GeneralTile *__restrict__ tiles, int n_tiles, double *__re
 
 // what: bit 0 inputs (solar, ir), bit 1 outputs (hs, flow)
 __global__ void __launch_bounds__(256)
-k_surf_scalars(int n_surf, SlotArrays sl, SurfArrays sa, double *__restrict__ solar_f, double *__restrict__ solar_b,
-               double *__restrict__ ir_f, double *__restrict__ ir_b, double *__restrict__ state, int to_state,
-               int what) {
+k_surf_scalars(int n_surf, SlotArrays sl, SideDyn *__restrict__ dyn, SideOut *__restrict__ out,
+               double *__restrict__ state, int to_state, int what) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_surf) return;
+    const int S = n_surf;
     if (to_state) {
         if (what & 2) {
-            state[sl.hs_f[d]] = sa.hs_f[d];
-            state[sl.hs_b[d]] = sa.hs_b[d];
-            state[sl.flow_f[d]] = sa.flow_f[d];
-            state[sl.flow_b[d]] = sa.flow_b[d];
+            const SideOut f = out[d], b = out[S + d];
+            state[sl.hs_f[d]] = f.hs;
+            state[sl.hs_b[d]] = b.hs;
+            state[sl.flow_f[d]] = f.flow;
+            state[sl.flow_b[d]] = b.flow;
         }
     } else {
         if (what & 1) {
-            solar_f[d] = state[sl.solar_f[d]];
-            solar_b[d] = state[sl.solar_b[d]];
-            ir_f[d] = state[sl.ir_f[d]];
-            ir_b[d] = state[sl.ir_b[d]];
+            // solar clamps of ThermalSurfaceData::march (surface.rs:916-923): front NaN or < 0 -> 0;
+            // back only NaN -> 0 (its second clause tests solar_front, already clamped)
+            double sf = state[sl.solar_f[d]];
+            if (sf != sf || sf < 0.0) sf = 0.0;
+            double sb = state[sl.solar_b[d]];
+            if (sb != sb) sb = 0.0;
+            SideDyn f, b;
+            f.solar = sf;
+            f.rad_t = ir_to_rad_temperature(state[sl.ir_f[d]]);
+            b.solar = sb;
+            b.rad_t = ir_to_rad_temperature(state[sl.ir_b[d]]);
+            dyn[d] = f;
+            dyn[S + d] = b;
         }
         if (what & 2) {
-            sa.hs_f[d] = state[sl.hs_f[d]];
-            sa.hs_b[d] = state[sl.hs_b[d]];
-            sa.flow_f[d] = state[sl.flow_f[d]];
-            sa.flow_b[d] = state[sl.flow_b[d]];
+            SideOut f, b;
+            f.hs = state[sl.hs_f[d]];
+            b.hs = state[sl.hs_b[d]];
+            f.flow = state[sl.flow_f[d]];
+            b.flow = state[sl.flow_b[d]];
+            out[d] = f;
+            out[S + d] = b;
         }
     }
 }
@@ -640,20 +732,31 @@ __global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
 // Launch wrappers (host).
 static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
 
-void launch_surfaces_fast(int M, const FastTile *tiles, int n_tiles, const NodeArrays &na, const SurfArrays &sa,
-                          const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
-                          int *flags, hipStream_t st) {
+void launch_surfaces_fast(int M, int nm, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+                          const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
+                          const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
     if (n_tiles <= 0) return;
     const dim3 grid(blocks_for_waves(n_tiles)), block(256);
-    switch (M) {
-    case 4: hipLaunchKernelGGL(k_surfaces_fast<4>, grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, step_fixed, zone_T, flags); break;
-    case 8: hipLaunchKernelGGL(k_surfaces_fast<8>, grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, step_fixed, zone_T, flags); break;
-    default: hipLaunchKernelGGL(k_surfaces_fast<16>, grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, step_fixed, zone_T, flags); break;
+#define HEAT_LAUNCH_FAST(MM, NN, VV)                                                                              \
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, VV>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, \
+                       step_fixed, zone_T, flags, nomass_iters)
+    static const int var = getenv("HEAT_AMD_VARIANT") ? atoi(getenv("HEAT_AMD_VARIANT")) : 0;  // ablation builds (dev only)
+    if (M == 8 && nm == 0 && var == 1) { HEAT_LAUNCH_FAST(8, 0, 1); return; }
+    if (M == 8 && nm == 0 && var == 2) { HEAT_LAUNCH_FAST(8, 0, 2); return; }
+    if (M == 8 && nm == 0 && var == 3) { HEAT_LAUNCH_FAST(8, 0, 3); return; }
+    switch (M * 2 + (nm ? 1 : 0)) {
+    case 8: HEAT_LAUNCH_FAST(4, 0, 0); break;
+    case 9: HEAT_LAUNCH_FAST(4, 1, 0); break;
+    case 16: HEAT_LAUNCH_FAST(8, 0, 0); break;
+    case 17: HEAT_LAUNCH_FAST(8, 1, 0); break;
+    case 32: HEAT_LAUNCH_FAST(16, 0, 0); break;
+    default: HEAT_LAUNCH_FAST(16, 1, 0); break;
     }
+#undef HEAT_LAUNCH_FAST
 }
 
 void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
-                             const SurfArrays &sa, const CavityDev *cavs, double *scratch,
+                             const SideArrays &sa, const CavityDev *cavs, double *scratch,
                              const StepWeather *weather, const int *step_ptr, int step_fixed,
                              const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
     if (n_tiles <= 0) return;
@@ -661,7 +764,7 @@ void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeAr
                        gen_base, sa, cavs, scratch, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
 }
 
-void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const double *hs,
+void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, hipStream_t st) {
     const int nb = n_zones > 0 ? blocks_for_waves(n_zones) : 1;
@@ -695,11 +798,11 @@ void launch_nodes_general(const GeneralTile *tiles, int n_tiles, double *Tbuf, c
                        meta, first_slot, state, to_state);
 }
 
-void launch_surf_scalars(int n_surf, const SlotArrays &sl, const SurfArrays &sa, double *solar_f, double *solar_b,
-                         double *ir_f, double *ir_b, double *state, int to_state, int what, hipStream_t st) {
+void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, double *state, int to_state,
+                         int what, hipStream_t st) {
     if (n_surf <= 0) return;
-    hipLaunchKernelGGL(k_surf_scalars, dim3((n_surf + 255) / 256), dim3(256), 0, st, n_surf, sl, sa, solar_f,
-                       solar_b, ir_f, ir_b, state, to_state, what);
+    hipLaunchKernelGGL(k_surf_scalars, dim3((n_surf + 255) / 256), dim3(256), 0, st, n_surf, sl, dyn, out, state,
+                       to_state, what);
 }
 
 void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, double *state, int to_state,

@@ -10,14 +10,14 @@ struct SlotArrays {
     const int64_t *hs_f, *hs_b, *flow_f, *flow_b, *solar_f, *solar_b, *ir_f, *ir_b;
 };
 
-void launch_surfaces_fast(int M, const FastTile *tiles, int n_tiles, const NodeArrays &na, const SurfArrays &sa,
-                          const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
-                          int *flags, hipStream_t st);
+void launch_surfaces_fast(int M, int nm, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+                          const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
+                          const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st);
 void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
-                             const SurfArrays &sa, const CavityDev *cavs, double *scratch,
+                             const SideArrays &sa, const CavityDev *cavs, double *scratch,
                              const StepWeather *weather, const int *step_ptr, int step_fixed,
                              const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st);
-void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const double *hs,
+void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, hipStream_t st);
 void launch_zone_update(const double *gathered, int n_blocks, const double *a0, const double *b0,
@@ -27,8 +27,8 @@ void launch_nodes_fast(int M, const FastTile *tiles, int n_tiles, double *Tbuf, 
                        const int64_t *first_slot, double *state, int to_state, hipStream_t st);
 void launch_nodes_general(const GeneralTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
                           const int64_t *first_slot, double *state, int to_state, hipStream_t st);
-void launch_surf_scalars(int n_surf, const SlotArrays &sl, const SurfArrays &sa, double *solar_f, double *solar_b,
-                         double *ir_f, double *ir_b, double *state, int to_state, int what, hipStream_t st);
+void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, double *state, int to_state,
+                         int what, hipStream_t st);
 void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, double *state, int to_state,
                          hipStream_t st);
 void launch_set_step(int *step_ptr, int v, hipStream_t st);

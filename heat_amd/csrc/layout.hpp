@@ -46,21 +46,39 @@ struct GeneralTile {
     int64_t scratch_base;  // in doubles, into the scratch buffer; [array][n_max][64]
 };
 
-// Per-surface structure of arrays (device pointers), indexed by device surface d.
-struct SurfArrays {
-    // packed: n_nodes | front_kind << 16 | back_kind << 18 | flags << 20
-    const int32_t *meta;
-    const int32_t *front_zone, *back_zone;
-    const double *front_ambient, *back_ambient;
-    const double *front_emis, *back_emis;
-    const double *area, *perimeter;
-    const double *cos_tilt, *normal_x, *normal_y, *wind_mod;
-    const double *alpha_f0, *alpha_bn;      // opaque shortcut: absorptance of first / last node
-    const double *hs_fix_f, *hs_fix_b;      // nullable
-    // inputs written by other modules between marches
-    const double *solar_f, *solar_b, *ir_f, *ir_b;
-    // outputs
-    double *hs_f, *hs_b, *flow_f, *flow_b;
+// Per-surface data is kept per SIDE (front = side 0, back = side 1), record index = side * S + d
+// for device surface d, so that the lane that evaluates a side fetches it with a few 16-byte loads.
+//
+// Constants of one side (64 bytes).
+struct alignas(16) SideConst {
+    int32_t kind_n;   // bits 0-1: boundary kind; bit 2: always windward (|cos tilt| >= 0.98,
+                      // reference src/surface.rs:38); bits 16-31: node count of the surface
+    int32_t zone;     // zone index when kind == KIND_SPACE
+    double ambient;   // Boundary::AmbientTemperature { temperature }
+    double emis;      // thermal emissivity of this face (src/surface.rs:335,338)
+    double alpha;     // solar absorptance of the face node (front_alphas[0] / back_alphas[n-1])
+    double cos_eff;   // cos_surface_tilt as this side's ConvectionParams takes it (front Outdoor: -cos)
+    double forced;    // 2.537 * 1.67 * sqrt(perimeter * wind_modifier / area)  (src/convection.rs:157-163)
+    double nx, ny;    // surface normal (for is_windward)
+};
+// Inputs other modules write between marches, converted once at upload.
+struct alignas(16) SideDyn {
+    double solar;     // incident solar irradiance, clamped as src/surface.rs:916-923 does
+    double rad_t;     // (ir / sigma)^0.25 - 273.15 (src/surface.rs:647,692)
+};
+// Outputs of iterate_surfaces (src/model.rs:154-169).
+struct alignas(16) SideOut {
+    double hs;        // convection coefficient
+    double flow;      // convective heat flow
+};
+
+struct SideArrays {
+    const SideConst *sc;   // [2 * S]
+    const SideDyn *dyn;    // [2 * S]
+    SideOut *out;          // [2 * S]
+    const double *hs_fix;  // [2 * S] debug overrides (src/surface.rs:374-380), NaN = none; nullable
+    int32_t S;
+    int32_t pad;
 };
 
 // Unified per-node buffers (all groups).
@@ -81,12 +99,14 @@ struct CavityDev {
 
 // Weather and per-march constants, device-resident. step is advanced by the zone kernel.
 struct StepWeather {
-    double t_out, wind_speed, sin_wd, cos_wd;
+    double t_out;    // dry bulb
+    double sqrt_ws;  // sqrt(wind speed): the forced coefficient is wf * SideConst::forced * sqrt_ws
+    double sin_wd, cos_wd;
 };
 
 struct ZoneEntry {
     uint32_t t_index;   // index into NodeArrays::T of the face node
-    uint32_t hs_index;  // index into the concatenated [hs_f | hs_b] buffer
+    uint32_t hs_index;  // side record index (side * S + d) into SideArrays::out
     double area;
 };
 

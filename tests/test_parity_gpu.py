@@ -208,3 +208,29 @@ def test_sharded_march_single_rank_nccl():
     r = subprocess.run([sys.executable, os.path.join(here, "sharded_nccl_worker.py")], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "SHARDED OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("n,npl,which", [(3, 4, "both"), (5, 4, "front"), (9, 8, "back"), (9, 4, "both"), (17, 8, "both"),
+                                          (8, 8, "both"), (33, 16, "back"), (2, 4, "front"), (2, 4, "back"), (40, 8, "both")])
+def test_no_mass_facings_on_the_fast_path(oracle, n, npl, which):
+    """Walls whose face node(s) carry no mass (one-node no-mass chunks, surface.rs:790-898), for node counts
+    that put the facing alone in a lane, at a lane boundary, or in a single-lane surface."""
+    md, st = mdl.uniform_massive(333, n, Z=4, dt=45.0, seed=n + npl)
+    off = md["node_offset"]
+    mass = md["mass"].copy()
+    u = md["uvalue"].copy()
+    rng = np.random.default_rng(n)
+    if which in ("front", "both"):
+        mass[off[:-1]] = 0.0
+        u[off[:-1]] = rng.uniform(0.5, 3.0, 333)
+    if which in ("back", "both"):
+        mass[off[1:] - 1] = 0.0
+        u[off[1:] - 2] = rng.uniform(0.5, 3.0, 333)
+    md["mass"], md["uvalue"] = mass, u
+    md["front_emissivity"] = md["front_emissivity"] * 0.2
+    md["back_emissivity"] = md["back_emissivity"] * 0.2
+    w = mdl.weather_series(20, 45.0)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
+    assert counts[3] == 0, counts  # all on the fast path
+    assert iters == gpu_iters and iters > 0
+    assert_state_close(md, ref, got)
