@@ -85,6 +85,23 @@ def cpu_baseline(n, dt, seed, target_seconds=12.0):
     return out
 
 
+def pmc_traffic(surfaces, nodes):
+    """HBM bytes per launch of the surface kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; bench.py cannot run the profiler on itself). None when no
+    committed measurement matches this workload."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_pmc_traffic.json"):
+            try:
+                j = json.load(open(os.path.join(pdir, f)))
+            except Exception:
+                continue
+            if j.get("workload", {}).get("surfaces") == surfaces and j.get("workload", {}).get("nodes") == nodes:
+                best = (j["traffic_bytes_per_launch"], "profiles/" + f)
+    return best if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,16 +196,17 @@ def main():
                         "(iterate_surfaces + zone update)" % (args.surfaces, args.nodes, args.zones_per_gpu, dt),
             "surfaces_per_gpu": args.surfaces, "nodes_per_surface": args.nodes,
             "zones_per_gpu": args.zones_per_gpu, "dt_s": dt,
-            "kernel_classes[M4,M8,M16,general]": counts,
+            "kernel_classes[M4,M8,M16,small,general]": counts,
             "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep all-gather of zone partials" % world
             if world > 1 else "single GPU",
         },
     }
     if n_samples > 0:
         achieved = algorithmic_bytes / (surf_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(args.surfaces, args.nodes)
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_surfaces_fast (iterate_surfaces: RK4 stencil + boundary updates)",
             "algorithmic_bytes_per_launch": algorithmic_bytes,
             "kernel_us": surf_us, "substep_us": substep_us, "samples": n_samples,

@@ -297,6 +297,6 @@ class HeatBatch:
         return self._L.heat_batch_nomass_iterations(self._h)
 
     def class_counts(self):
-        c = (C.c_int64 * 4)()
+        c = (C.c_int64 * 5)()
         _check(self._L.heat_batch_class_counts(self._h, c))
         return list(c)

@@ -75,7 +75,8 @@ constexpr int kScratchArrays = 7;
 constexpr int kNumFast = 6;                       // fast classes: (M, no-mass facings allowed)
 const int kFastM[kNumFast] = {4, 4, 8, 8, 16, 16};
 const int kFastNM[kNumFast] = {0, 1, 0, 1, 0, 1};
-constexpr int kGeneral = kNumFast;
+constexpr int kSmall = kNumFast;        // all-no-mass surfaces of <= 4 nodes (general layout, register kernel)
+constexpr int kGeneral = kNumFast + 1;  // catch-all
 
 }  // namespace
 
@@ -89,12 +90,14 @@ struct heat_batch {
     int64_t n_surf = 0, n_zones = 0, n_state = 0, n_nodes = 0, n_cav = 0;
     double dt = 0;
     int64_t algorithmic_bytes = 0;
-    int64_t class_counts[4] = {0, 0, 0, 0};
+    int64_t class_counts[5] = {0, 0, 0, 0, 0};  // M4, M8, M16, small, general
 
     // layout
     int n_fast_tiles[kNumFast] = {0, 0, 0, 0, 0, 0};
     DevBuf<FastTile> d_fast_tiles[kNumFast];
-    int n_gen_tiles = 0;
+    int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
+    int n_small_tiles = 0;
+    size_t nm_count_base[kNumFast + 1] = {0, 0, 0, 0, 0, 0, 0};
     DevBuf<GeneralTile> d_gen_tiles;
     int64_t gen_base = 0;     // first node slot of the general group
     int64_t node_slots = 0;   // total node slots incl. padding
@@ -164,8 +167,13 @@ struct Placed {
 // face nodes may be no-mass facings (each then is an isolated one-node no-mass chunk).
 int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
     if (opt.force_general) return kGeneral;
-    if (n < 2) return kGeneral;
     const int64_t o = d->node_offset[s];
+    if (n <= 4) {
+        bool all_nomass = true;
+        for (int i = 0; i < n; i++) all_nomass = all_nomass && (d->mass[o + i] < kMassThreshold);
+        if (all_nomass) return kSmall;
+    }
+    if (n < 2) return kGeneral;
     int nm = 0;
     for (int i = 0; i < n; i++) {
         if (d->mass[o + i] < kMassThreshold) {
@@ -272,16 +280,16 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     for (int64_t s = 0; s < S; s++) {
         const int n = (int)(d->node_offset[s + 1] - d->node_offset[s]);
         const int cls = classify(d, s, n, opt);
-        const int M = cls < kGeneral ? kFastM[cls] : 0;
-        placed[s] = Placed{s, n, cls, cls < kGeneral ? (n + M - 1) / M : 1};
-        b->class_counts[cls < kGeneral ? cls / 2 : 3]++;
+        const int M = cls < kNumFast ? kFastM[cls] : 0;
+        placed[s] = Placed{s, n, cls, cls < kNumFast ? (n + M - 1) / M : 1};
+        b->class_counts[cls < kNumFast ? cls / 2 : (cls == kSmall ? 3 : 4)]++;
     }
     std::vector<int64_t> order(S);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
         const Placed &a = placed[x], &c = placed[y];
         if (a.cls != c.cls) return a.cls < c.cls;
-        if (a.cls < kGeneral) return a.k < c.k;
+        if (a.cls < kNumFast) return a.k < c.k;
         return a.n < c.n;
     });
 
@@ -298,7 +306,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     std::vector<NodeMap> nmap(S);
     while (pos < (size_t)S) {
         const Placed &p0 = placed[order[pos]];
-        if (p0.cls < kGeneral) {
+        if (p0.cls < kNumFast) {
             const int M = kFastM[p0.cls], k = p0.k;
             const int Gmax = kWave / k, Lk = Gmax * k;
             size_t end = pos;
@@ -322,7 +330,9 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             pos = end;
         } else {
             if (gen_tiles.empty()) b->gen_base = node_cursor;
-            size_t end = std::min(pos + (size_t)kWave, (size_t)S);
+            size_t end = pos;
+            while (end < (size_t)S && end < pos + (size_t)kWave && placed[order[end]].cls == p0.cls) end++;
+            if (p0.cls == kSmall) b->n_small_tiles++;
             int n_max = 0;
             for (size_t q = pos; q < end; q++) n_max = std::max(n_max, placed[order[q]].n);
             GeneralTile t;
@@ -365,7 +375,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         const int64_t s = orig_of[dd];
         const int64_t o = d->node_offset[s];
         const int n = placed[s].n;
-        const bool gen = placed[s].cls == kGeneral;
+        const bool gen = placed[s].cls >= kNumFast;
         for (int i = 0; i < n; i++) {
             const int64_t idx = node_index(dd, i);
             const double mass = d->mass[o + i];
@@ -504,7 +514,16 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_state.zeros(d->n_state));
     HIP_TRY(b->d_step.zeros(1));
     HIP_TRY(b->d_flags.zeros(1));
-    HIP_TRY(b->d_nomass_iters.zeros(1));
+    {   // no-mass pass counters: one slot per tile of the NM fast classes, one per lane of the general-layout tiles
+        size_t n = 0;
+        for (int c = 0; c < kNumFast; c++) {
+            b->nm_count_base[c] = n;
+            if (kFastNM[c]) n += fast_tiles[c].size();
+        }
+        b->nm_count_base[kNumFast] = n;
+        n += gen_tiles.size() * (size_t)kWave;
+        HIP_TRY(b->d_nomass_iters.zeros(std::max<size_t>(n, 1)));
+    }
     if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
 
     // ---- argument bundles ----
@@ -535,10 +554,15 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
     for (int c = 0; c < kNumFast; c++)
         launch_surfaces_fast(kFastM[c], kFastNM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa,
                              b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
-                             b->d_nomass_iters.p, b->stream);
-    launch_surfaces_general(b->d_gen_tiles.p, b->n_gen_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
-                            b->d_scratch.p, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
-                            b->d_nomass_iters.p, b->stream);
+                             b->d_nomass_iters.p + b->nm_count_base[c], b->stream);
+    launch_surfaces_small(b->d_gen_tiles.p, b->n_small_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
+                          b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
+                          b->d_nomass_iters.p + b->nm_count_base[kNumFast], b->stream);
+    launch_surfaces_general(b->d_gen_tiles.p + b->n_small_tiles, b->n_gen_tiles - b->n_small_tiles, b->na,
+                            b->gen_base, b->sa, b->d_cavs.p, b->d_scratch.p, b->d_weather.p, b->d_step.p,
+                            step_fixed, b->d_zone_T.p, b->d_flags.p,
+                            b->d_nomass_iters.p + b->nm_count_base[kNumFast] + (size_t)b->n_small_tiles * kWave,
+                            b->stream);
 }
 
 void enqueue_zones(heat_batch *b, int mode) {
@@ -629,9 +653,9 @@ int64_t heat_batch_n_surfaces(const heat_batch *b) { return b ? b->n_surf : 0; }
 int64_t heat_batch_n_nodes(const heat_batch *b) { return b ? b->n_nodes : 0; }
 int64_t heat_batch_n_zones(const heat_batch *b) { return b ? b->n_zones : 0; }
 int64_t heat_batch_algorithmic_bytes(const heat_batch *b) { return b ? b->algorithmic_bytes : 0; }
-int heat_batch_class_counts(const heat_batch *b, int64_t counts[4]) {
+int heat_batch_class_counts(const heat_batch *b, int64_t counts[5]) {
     if (!b || !counts) return fail(HEAT_E_INVALID_ARG, "NULL argument");
-    for (int i = 0; i < 4; i++) counts[i] = b->class_counts[i];
+    for (int i = 0; i < 5; i++) counts[i] = b->class_counts[i];
     return HEAT_OK;
 }
 
@@ -837,8 +861,12 @@ int64_t heat_batch_nomass_iterations(heat_batch *b) {
     if (!b) return 0;
     if (hipSetDevice(b->device) != hipSuccess) return -1;
     if (hipStreamSynchronize(b->stream) != hipSuccess) return -1;
+    std::vector<unsigned long long> h(b->d_nomass_iters.n);
+    if (hipMemcpy(h.data(), b->d_nomass_iters.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) !=
+        hipSuccess)
+        return -1;
     unsigned long long v = 0;
-    if (hipMemcpy(&v, b->d_nomass_iters.p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (unsigned long long x : h) v += x;
     return (int64_t)v;
 }
 

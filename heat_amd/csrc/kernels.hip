@@ -334,7 +334,11 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     }
     if (active && bad) atomicOr(flags, bad);
     if constexpr (NM) {
-        if (nm_passes) atomicAdd(nomass_iters, (unsigned long long)nm_passes);
+        // passes of the no-mass loop, summed per tile (one owner per slot: no atomics on a shared word)
+        unsigned int tot = nm_passes;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
+        if (lane == 0 && tot) nomass_iters[wave] += tot;
     }
 }
 
@@ -549,9 +553,161 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
         sd.out[S + d] = ob;
     }
     if (bad) atomicOr(flags, bad);
-    if (iters) atomicAdd(nomass_iters, iters);
+    if (iters) nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
 #undef SC
 #undef TT
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// Small all-no-mass surfaces (n <= 4: single-layer no-mass walls, double glazing with its gas
+// cavity): one lane per surface, the whole chunk (0, n) in registers. Same layout as the general
+// group, reference operation order (march_nomass, surface.rs:790-898), no FMA contraction.
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256)
+k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
+                 SideArrays sd, const CavityDev *__restrict__ cavs,
+                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                 const double *__restrict__ zone_T, int *__restrict__ flags,
+                 unsigned long long *__restrict__ nomass_iters) {
+    constexpr int NS = 4;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+    const GeneralTile tile = tiles[wave];
+    if (lane >= tile.G) return;
+    const int d = tile.surf_base + lane;
+    const int S = sd.S;
+
+    const SideConst cf = sd.sc[d];
+    const SideConst cb = sd.sc[S + d];
+    const SideDyn df = sd.dyn[d];
+    const SideDyn db = sd.dyn[S + d];
+    const int nn = cf.kind_n >> 16;
+    const int bk = cb.kind_n & 3;
+    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const StepWeather w = weather[step];
+
+    double *Tg = na.T + tile.node_base + lane;
+    const double *Ug = na.U + tile.node_base + lane;
+    const int64_t gofs = tile.node_base - gen_base + lane;
+    double T[NS], Us[NS], sol[NS];
+    int cav[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const bool v = j < nn;
+        T[j] = v ? Tg[(int64_t)j * kWave] : 0.0;
+        Us[j] = v ? Ug[(int64_t)j * kWave] : 0.0;
+        cav[j] = v ? na.cav[gofs + (int64_t)j * kWave] : -1;
+        // surface.rs:930-931
+        double sj = v ? na.alpha_f[gofs + (int64_t)j * kWave] * df.solar : 0.0;
+        sj += v ? na.alpha_b[gofs + (int64_t)j * kWave] * db.solar : 0.0;
+        sol[j] = sj;
+    }
+
+    int bad = 0;
+    const double t_front_b = boundary_temperature(cf, w, zone_T);
+    const double t_back_b = boundary_temperature(cb, w, zone_T);
+    auto last = [&](const double (&x)[NS]) {
+        double r = x[0];
+#pragma unroll
+        for (int j = 1; j < NS; j++) r = (j == nn - 1) ? x[j] : r;
+        return r;
+    };
+    const double T0 = T[0], Tn = last(T);
+    const bool quirk = (bk == KIND_AMBIENT);
+    double f_hs, f_rad, b_hs, b_rad;
+    const double f_surf = T0, b_surf = quirk ? T0 : Tn;
+    eval_side(cf, w, t_front_b, t_front_b, df.rad_t, f_surf, f_hs, f_rad, bad);
+    eval_side(cb, w, t_back_b, quirk ? t_front_b : t_back_b, db.rad_t, b_surf, b_hs, b_rad, bad);
+    if (f_hs != f_hs || b_hs != b_hs) bad |= FLAG_NAN_HS;
+    if (sd.hs_fix != nullptr) {
+        const double ff = sd.hs_fix[d], fb = sd.hs_fix[S + d];
+        if (ff == ff) f_hs = ff;
+        if (fb == fb) b_hs = fb;
+    }
+    const double f_radhs = rad_hs(cf.emis, f_rad, f_surf);
+    const double b_radhs = rad_hs(cb.emis, b_rad, b_surf);
+
+    unsigned int iters = 0;
+    double old_err = 99999.;
+    int count = 0;
+    for (;;) {
+        // get_k_q for the chunk (0, nn) — discretization.rs:596-700
+        double lo[NS], dg[NS], up[NS], q[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) { lo[j] = 0.0; dg[j] = 0.0; up[j] = 0.0; q[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < NS - 1; j++) {
+            if (j < nn - 1) {
+                double u = Us[j];
+                if (cav[j] >= 0) u = cavity_u_value(cavs[cav[j]], T[j], T[j + 1], bad);
+                dg[j] += -u;
+                dg[j + 1] = dg[j + 1] - u;
+                up[j] = up[j] + u;
+                lo[j + 1] = lo[j + 1] + u;
+            }
+        }
+        q[0] += t_front_b * f_hs + f_radhs * (f_rad - T[0]);
+        dg[0] += -f_hs;
+        const double bq = t_back_b * b_hs + b_radhs * (b_rad - last(T));
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            if (j == nn - 1) { q[j] += bq; dg[j] += -b_hs; }
+        }
+        iters++;
+#pragma unroll
+        for (int j = 0; j < NS; j++) q[j] = (q[j] + sol[j]) * -1.;  // surface.rs:828-832
+        // mut_n_diag_gaussian(q, 3)
+#pragma unroll
+        for (int j = 1; j < NS; j++) {
+            if (j < nn) {
+                const double f = lo[j] / dg[j - 1];
+                dg[j] -= f * up[j - 1];
+                q[j] -= f * q[j - 1];
+            }
+        }
+        double x[NS];
+#pragma unroll
+        for (int j = NS - 1; j >= 0; j--) {
+            if (j == nn - 1) x[j] = q[j] / dg[j];
+            else if (j < nn - 1) x[j] = (q[j] - up[j] * x[(j + 1) % NS]) / dg[j];
+            else x[j] = 0.0;
+        }
+        double err = 0.0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) if (j < nn) err += fabs(x[j] - T[j]);
+        if (err > old_err) break;                            // surface.rs:842-848
+        if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
+#pragma unroll
+        for (int j = 0; j < NS; j++) if (j < nn) T[j] = (T[j] + x[j]) * 0.5;
+        const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
+        if (err / (double)nn < tol) break;
+        old_err = err;
+        count++;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
+
+    {   // outputs with the new surface temperatures (model.rs:150-169)
+        const double T0n = T[0], Tnn = last(T);
+        double fh, bh, r_;
+        eval_side(cf, w, t_front_b, t_front_b, df.rad_t, T0n, fh, r_, bad);
+        eval_side(cb, w, t_back_b, t_back_b, db.rad_t, quirk ? T0n : Tnn, bh, r_, bad);
+        if (fh != fh || bh != bh) bad |= FLAG_NAN_HS;
+        if (sd.hs_fix != nullptr) {
+            const double ff = sd.hs_fix[d], fb = sd.hs_fix[S + d];
+            if (ff == ff) fh = ff;
+            if (fb == fb) bh = fb;
+        }
+        SideOut of, ob;
+        of.hs = fh; of.flow = (T0n - t_front_b) * fh;
+        ob.hs = bh; ob.flow = (Tnn - t_back_b) * bh;
+        sd.out[d] = of;
+        sd.out[S + d] = ob;
+    }
+    if (bad) atomicOr(flags, bad);
+    nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
 }
 #pragma clang fp contract(fast)
 
@@ -762,6 +918,15 @@ void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeAr
     if (n_tiles <= 0) return;
     hipLaunchKernelGGL(k_surfaces_general, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, na,
                        gen_base, sa, cavs, scratch, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
+}
+
+void launch_surfaces_small(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
+                           const SideArrays &sa, const CavityDev *cavs, const StepWeather *weather,
+                           const int *step_ptr, int step_fixed, const double *zone_T, int *flags,
+                           unsigned long long *nomass_iters, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_surfaces_small, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, na,
+                       gen_base, sa, cavs, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
 }
 
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,

@@ -194,8 +194,8 @@ int64_t heat_batch_n_zones(const heat_batch *b);
 int64_t heat_batch_algorithmic_bytes(const heat_batch *b);
 /* Total iterations of the no-mass fixed-point loop (surface.rs:808-896) since creation. */
 int64_t heat_batch_nomass_iterations(heat_batch *b);
-/* Number of surfaces routed to {fast M=4, M=8, M=16, general}. */
-int heat_batch_class_counts(const heat_batch *b, int64_t counts[4]);
+/* Number of surfaces routed to {fast M=4, fast M=8, fast M=16, small all-no-mass, general catch-all}. */
+int heat_batch_class_counts(const heat_batch *b, int64_t counts[5]);
 /* Kernel timing with HIP events recorded on the batch's stream around the surface kernels of
  * every sub-timestep executed while enabled (the march then runs eagerly, not as a graph).
  * heat_batch_get_timing synchronises and returns the mean duration in microseconds of the

@@ -1,0 +1,18 @@
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+from heat_amd import HeatBatch, modeldict as mdl
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+which = sys.argv[2] if len(sys.argv) > 2 else "ragged"
+if which == "ragged":
+    md, st = mdl.ragged_mixed(S, dt=45.0)
+elif which == "glazing":
+    md, st = mdl.glazing_cavity(S, dt=45.0)
+else:
+    md, st = mdl.uniform_massive(S, 32, dt=45.0)
+w = mdl.weather_series(20, 45.0)
+with HeatBatch(md) as b:
+    b.upload_state(st)
+    b.march_resident(w); b.synchronize()
+    b.set_timing(True); b.march_resident(w); b.synchronize()
+    print(which, b.class_counts(), b.get_timing())
