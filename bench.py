@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--zones-per-gpu", type=int, default=10_000)
     ap.add_argument("--nodes-per-lane", type=int, default=0)
+    ap.add_argument("--no-palette", action="store_true", help="keep dt/mass and U as per-node arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
     args = ap.parse_args()
@@ -136,7 +137,8 @@ def main():
         from heat_amd.sharded import ShardedMarch
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        sm = ShardedMarch(md, rank, world, device_index=local_rank, nodes_per_lane=args.nodes_per_lane)
+        sm = ShardedMarch(md, rank, world, device_index=local_rank, nodes_per_lane=args.nodes_per_lane,
+                          no_palette=args.no_palette)
         batch = sm.batch
         batch.upload_state(state)
 
@@ -146,7 +148,8 @@ def main():
 
         run = sm.march_resident
     else:
-        batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True)
+        batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True,
+                          no_palette=args.no_palette)
         batch.upload_state(state)
 
         def barrier():

@@ -61,7 +61,8 @@ class Desc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("force_general", C.c_int32), ("nodes_per_lane", C.c_int32),
-                ("use_graph", C.c_int32), ("stream", C.c_void_p), ("n_ranks", C.c_int32), ("rank", C.c_int32)]
+                ("use_graph", C.c_int32), ("stream", C.c_void_p), ("n_ranks", C.c_int32), ("rank", C.c_int32),
+                ("no_palette", C.c_int32), ("reserved", C.c_int32)]
 
 
 # Every symbol include/heat_amd.h declares: (name, restype, argtypes)
@@ -188,7 +189,7 @@ class HeatBatch:
     """Device-resident batch of surfaces + zones (≙ ThermalModel, src/model.rs:54-77)."""
 
     def __init__(self, md, device=-1, force_general=False, nodes_per_lane=0, use_graph=False, stream=None,
-                 n_ranks=1, rank=0):
+                 n_ranks=1, rank=0, no_palette=False):
         self._L = load_library()
         self._h = _H()
         desc, keep = make_desc(md)
@@ -200,6 +201,7 @@ class HeatBatch:
         opt.stream = stream
         opt.n_ranks = n_ranks
         opt.rank = rank
+        opt.no_palette = 1 if no_palette else 0
         _check(self._L.heat_batch_create_ex(C.byref(desc), C.byref(opt), C.byref(self._h)))
         self.n_state = int(md["n_state"])
         self.n_zones = int(md["n_zones"])

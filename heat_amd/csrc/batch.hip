@@ -72,9 +72,10 @@ struct DevBuf {
 
 constexpr int kMaxNodesGeneral = 4096;
 constexpr int kScratchArrays = 7;
-constexpr int kNumFast = 6;                       // fast classes: (M, no-mass facings allowed)
-const int kFastM[kNumFast] = {4, 4, 8, 8, 16, 16};
-const int kFastNM[kNumFast] = {0, 1, 0, 1, 0, 1};
+constexpr int kNumFast = 12;  // fast classes: (M, no-mass facings allowed, palette constants)
+const int kFastM[kNumFast] = {4, 4, 4, 4, 8, 8, 8, 8, 16, 16, 16, 16};
+const int kFastNM[kNumFast] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1};
+const int kFastPAL[kNumFast] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
 constexpr int kSmall = kNumFast;        // all-no-mass surfaces of <= 4 nodes (general layout, register kernel)
 constexpr int kGeneral = kNumFast + 1;  // catch-all
 
@@ -91,19 +92,22 @@ struct heat_batch {
     double dt = 0;
     int64_t algorithmic_bytes = 0;
     int64_t class_counts[5] = {0, 0, 0, 0, 0};  // M4, M8, M16, small, general
+    int64_t n_palette = 0;                      // surfaces whose constants are in palette form
 
     // layout
-    int n_fast_tiles[kNumFast] = {0, 0, 0, 0, 0, 0};
+    int n_fast_tiles[kNumFast] = {};
     DevBuf<FastTile> d_fast_tiles[kNumFast];
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
     int n_small_tiles = 0;
-    size_t nm_count_base[kNumFast + 1] = {0, 0, 0, 0, 0, 0, 0};
+    size_t nm_count_base[kNumFast + 1] = {};
     DevBuf<GeneralTile> d_gen_tiles;
     int64_t gen_base = 0;     // first node slot of the general group
     int64_t node_slots = 0;   // total node slots incl. padding
 
     DevBuf<double> d_T, d_V, d_U, d_alpha_f, d_alpha_b, d_mass, d_scratch;
     DevBuf<int32_t> d_cav_idx;
+    DevBuf<uint8_t> d_cls;   // palette class bytes (PAL fast classes)
+    DevBuf<double> d_pal;    // palettes, kPal doubles per device surface
     DevBuf<CavityDev> d_cavs;
 
     DevBuf<int32_t> d_meta;        // node count per device surface (upload/download kernels)
@@ -194,7 +198,26 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
     }
     const int k = (n + M - 1) / M;
     if (k > kWave) return kGeneral;
-    return (M == 4 ? 0 : (M == 8 ? 2 : 4)) + nm;
+    // Palette form when the wall has few distinct constants (entry 0 of each palette is 0.0).
+    int pal = opt.no_palette ? 0 : 1;
+    if (pal) {
+        double vv[kPalV], uu[kPalU];
+        int nv = 1, nu = 1;
+        vv[0] = 0.0;
+        uu[0] = 0.0;
+        for (int i = 0; i < n && pal; i++) {
+            const double mass = d->mass[o + i];
+            const double v = (mass >= kMassThreshold) ? d->dt / mass : 0.0;
+            const double u = d->uvalue[o + i];
+            int f = -1;
+            for (int q = 0; q < nv; q++) if (vv[q] == v) f = q;
+            if (f < 0) { if (nv == kPalV) pal = 0; else vv[nv++] = v; }
+            f = -1;
+            for (int q = 0; q < nu; q++) if (uu[q] == u) f = q;
+            if (f < 0) { if (nu == kPalU) pal = 0; else uu[nu++] = u; }
+        }
+    }
+    return (M == 4 ? 0 : (M == 8 ? 4 : 8)) + nm * 2 + pal;
 }
 
 int check_desc(const heat_batch_desc *d) {
@@ -282,7 +305,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         const int cls = classify(d, s, n, opt);
         const int M = cls < kNumFast ? kFastM[cls] : 0;
         placed[s] = Placed{s, n, cls, cls < kNumFast ? (n + M - 1) / M : 1};
-        b->class_counts[cls < kNumFast ? cls / 2 : (cls == kSmall ? 3 : 4)]++;
+        b->class_counts[cls < kNumFast ? cls / 4 : (cls == kSmall ? 3 : 4)]++;
+        if (cls < kNumFast && kFastPAL[cls]) b->n_palette++;
     }
     std::vector<int64_t> order(S);
     std::iota(order.begin(), order.end(), 0);
@@ -304,8 +328,11 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     size_t pos = 0;
     struct NodeMap { int64_t base; int Lk; int k; int M; int g; };  // per device surface
     std::vector<NodeMap> nmap(S);
+    int prev_cls = -1;
     while (pos < (size_t)S) {
         const Placed &p0 = placed[order[pos]];
+        if (p0.cls != prev_cls) node_cursor = (node_cursor + 15) / 16 * 16;  // class bytes are loaded 4/8/16 at a time
+        prev_cls = p0.cls;
         if (p0.cls < kNumFast) {
             const int M = kFastM[p0.cls], k = p0.k;
             const int Gmax = kWave / k, Lk = Gmax * k;
@@ -313,10 +340,12 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].k == k &&
                    (int)(end - pos) < Gmax)
                 end++;
+            bool all_full = true;
+            for (size_t q = pos; q < end; q++) all_full = all_full && (placed[order[q]].n == k * M);
             FastTile t;
             t.node_base = node_cursor;
             t.surf_base = (int32_t)dcur;
-            t.k = (int16_t)k;
+            t.k = (int16_t)(k | (all_full ? 0x100 : 0));
             t.G = (int16_t)(end - pos);
             fast_tiles[p0.cls].push_back(t);
             for (size_t q = pos; q < end; q++) {
@@ -368,6 +397,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
 
     // ---- per-node constants ----
     std::vector<double> hV(node_cursor, 0.0), hU(node_cursor, 0.0);
+    std::vector<uint8_t> hCls(b->n_palette ? node_cursor : 0, 0);
+    std::vector<double> hPal(b->n_palette ? (size_t)S * kPal : 0, 0.0);
     const int64_t gen_slots = node_cursor - b->gen_base;
     std::vector<double> hAf(gen_slots, 0.0), hAb(gen_slots, 0.0), hMass(gen_slots, 0.0);
     std::vector<int32_t> hCav(gen_slots, -1);
@@ -376,12 +407,25 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         const int64_t o = d->node_offset[s];
         const int n = placed[s].n;
         const bool gen = placed[s].cls >= kNumFast;
+        const bool pal = !gen && kFastPAL[placed[s].cls];
+        int nv = 1, nu = 1;
+        double *pp = pal ? &hPal[(size_t)dd * kPal] : nullptr;
         for (int i = 0; i < n; i++) {
             const int64_t idx = node_index(dd, i);
             const double mass = d->mass[o + i];
             hV[idx] = (mass >= kMassThreshold) ? d->dt / mass : 0.0;  // dt / C, surface.rs:172
             const bool cav = d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0;
             hU[idx] = cav ? 0.0 : d->uvalue[o + i];
+            if (pal) {
+                int vc = -1, uc = -1;
+                for (int q = 0; q < nv; q++) if (pp[q] == hV[idx]) vc = q;
+                if (vc < 0) { vc = nv; pp[nv++] = hV[idx]; }
+                for (int q = 0; q < nu; q++) if (pp[kPalV + q] == hU[idx]) uc = q;
+                if (uc < 0) { uc = nu; pp[kPalV + nu++] = hU[idx]; }
+                const NodeMap &m = nmap[dd];
+                const int lane = m.g * m.k + i / m.M, j = i % m.M;
+                hCls[m.base + (int64_t)lane * m.M + j] = (uint8_t)(vc | (uc << 3));
+            }
             if (gen) {
                 const int64_t gi = idx - b->gen_base;
                 hAf[gi] = d->front_alpha[o + i];
@@ -480,6 +524,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_alpha_b.upload(hAb));
     HIP_TRY(b->d_mass.upload(hMass));
     HIP_TRY(b->d_cav_idx.upload(hCav));
+    HIP_TRY(b->d_cls.upload(hCls));
+    HIP_TRY(b->d_pal.upload(hPal));
     HIP_TRY(b->d_scratch.alloc(scratch_cursor));
     {
         std::vector<CavityDev> hc(d->n_cavities);
@@ -536,6 +582,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     sa.pad = 0;
     NodeArrays &na = b->na;
     na.T = b->d_T.p; na.V = b->d_V.p; na.U = b->d_U.p;
+    na.cls = b->d_cls.p; na.pal = b->d_pal.p;
     na.alpha_f = b->d_alpha_f.p; na.alpha_b = b->d_alpha_b.p; na.cav = b->d_cav_idx.p; na.mass = b->d_mass.p;
     SlotArrays &sl = b->sl;
     const int64_t *sp = b->d_slots.p;
@@ -552,7 +599,7 @@ int select_device(heat_batch *b) {
 // iterate_surfaces for every group (model.rs:388-408)
 void enqueue_surfaces(heat_batch *b, int step_fixed) {
     for (int c = 0; c < kNumFast; c++)
-        launch_surfaces_fast(kFastM[c], kFastNM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa,
+        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa,
                              b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
                              b->d_nomass_iters.p + b->nm_count_base[c], b->stream);
     launch_surfaces_small(b->d_gen_tiles.p, b->n_small_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,

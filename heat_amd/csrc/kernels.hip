@@ -14,8 +14,6 @@
 // No MFMA anywhere: this is an HBM-bound f64 stencil.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "device_math.hpp"
 #include "kernels.hpp"
 #include "layout.hpp"
@@ -56,10 +54,57 @@ __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __sh
 
 // ---------------------------------------------------------------------------
 // Fast path. One wavefront per tile; see layout.hpp for the lane blocking.
+//
+// One RK4 stage on  dT/dt = V (f_j - f_{j-1}),  f_j = U_j (x_{j+1} - x_j)  (surface.rs:228-308 in flux
+// form). The two faces enter as fluxes too: the front face is the "flux from the left" of node 0,
+// hF x_0 - qF, the back face the "flux to the right" of the last node, qB - hB x_last (these are the
+// K[0,0] -= hs / q[0] += ... terms of get_k_q, discretization.rs:658-697, before the row scaling by
+// dt/C of rearrange_k, surface.rs:168-187). Stage outputs are consumed at once: `acc` gathers
+// T + k1/6 + k2/3 + k3/3 (+ k4/6) in the reference's order (surface.rs:296-305) and the next stage's
+// input overwrites the current one in place (x_j is dead once f_j is formed).
+//   STAGE 0: in = T        acc = T + k/6     out = T + k/2
+//   STAGE 1: in = out      acc += k/3        out = T + k/2
+//   STAGE 2: in = out      acc += k/3        out = T + k
+//   STAGE 3: in = out                        out = acc + k/6   (the new temperatures)
+// FULL: every surface of the tile fills its last lane (n == k M), so the last node is j == M-1.
+template <int M, bool FULL, int STAGE>
+__device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in)[M], double (&out)[M],
+                                         double (&acc)[M], const double (&V)[M], const double (&U)[M], double UL,
+                                         bool is_first, bool is_last, int jl, double hF, double qF, double hB,
+                                         double qB, int lane) {
+    double xl = __shfl(in[M - 1], (lane + kWave - 1) & (kWave - 1), kWave);
+    const double xr = __shfl(in[0], (lane + 1) & (kWave - 1), kWave);
+    // never let another surface's value (possibly NaN) in: the first lane has no left neighbour
+    double fprev = is_first ? (hF * in[0] - qF) : UL * (in[0] - xl);
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const double xj = in[j];
+        double f;
+        if (j == M - 1) {
+            f = is_last ? 0.0 : U[j] * (xr - xj);  // the last lane's right neighbour belongs to another surface
+        } else {
+            f = U[j] * (in[j + 1] - xj);
+        }
+        if (FULL) {
+            if (j == M - 1) f = is_last ? (qB - hB * xj) : f;
+        } else {
+            f = (is_last && j == jl) ? (qB - hB * xj) : f;
+        }
+        const double k = V[j] * (f - fprev);
+        fprev = f;
+        if (STAGE == 0) { acc[j] = T[j] + k * (1.0 / 6.0); out[j] = T[j] + 0.5 * k; }
+        if (STAGE == 1) { acc[j] += k * (1.0 / 3.0); out[j] = T[j] + 0.5 * k; }
+        if (STAGE == 2) { acc[j] += k * (1.0 / 3.0); out[j] = T[j] + k; }
+        if (STAGE == 3) { out[j] = acc[j] + k * (1.0 / 6.0); }
+    }
+}
+
 // NM = 1: the surface may carry a no-mass FACING node (node 0 and/or node n-1, every other node
 // massive): each is a one-node no-mass chunk, solved by the reference's damped fixed-point loop
 // (march_nomass, surface.rs:790-898) in the face lane before the massive nodes march.
-template <int M, int NM, int VAR = 0>
+// PAL = 1: V and U come from the surface's palette (staged in LDS) through one class byte per node
+// instead of two doubles per node (layout.hpp).
+template <int M, int NM, int PAL>
 __global__ void __launch_bounds__(256)
 k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
@@ -70,7 +115,8 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     if (wave >= n_tiles) return;
 
     const FastTile tile = tiles[wave];
-    const int k = tile.k;
+    const int k = tile.k & 0xff;
+    const bool full = (tile.k & 0x100) != 0;
     const int G = tile.G;
     const int Lk = (kWave / k) * k;
     int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
@@ -81,9 +127,60 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const int d = tile.surf_base + g;
     const int ll = in_layout ? lane : 0;
 
+    // ---- side record of this lane: the first lane of a surface owns the front side, every other
+    // lane loads the back side (only the last lane's is used). k == 1: both sides, see below. ----
+    const int S = sd.S;
+    const bool is_first = (seg == 0);
+    const bool is_last = (seg == k - 1);
+    const bool my_back = !is_first;
+    const int sidx = (my_back ? S : 0) + d;
+    const SideConst c = sd.sc[sidx];
+    const SideDyn dy = sd.dyn[sidx];
+
     // ---- node data: T, V = dt/C, U (coalesced 16-byte loads) ----
     double T[M], V[M], U[M];
-    {
+    if constexpr (PAL) {
+        __shared__ double s_pal[4][kWave * kPal];
+        double *sp = s_pal[threadIdx.x >> 6];
+        {   // the palettes of this tile's surfaces: G * kPal contiguous doubles -> LDS
+            const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * kPal);
+            double2 *sp2 = reinterpret_cast<double2 *>(sp);
+            const int n2 = G * (kPal / 2);
+            for (int i = lane; i < n2; i += kWave) sp2[i] = gp[i];
+        }
+        unsigned char cb[M];
+        {
+            const unsigned char *pc = na.cls + tile.node_base + (int64_t)ll * M;
+            if constexpr (M == 4) {
+                const unsigned int w0 = *reinterpret_cast<const unsigned int *>(pc);
+#pragma unroll
+                for (int j = 0; j < 4; j++) cb[j] = (w0 >> (8 * j)) & 0xff;
+            } else {
+#pragma unroll
+                for (int q = 0; q < M / 8; q++) {
+                    const uint2 w0 = reinterpret_cast<const uint2 *>(pc)[q];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        cb[8 * q + j] = (w0.x >> (8 * j)) & 0xff;
+                        cb[8 * q + 4 + j] = (w0.y >> (8 * j)) & 0xff;
+                    }
+                }
+            }
+        }
+        const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
+#pragma unroll
+        for (int jp = 0; jp < M / 2; jp++) {
+            const double2 t = pT[jp * Lk + ll];
+            T[2 * jp] = t.x; T[2 * jp + 1] = t.y;
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS writes above are ordered before the reads below (same wave)
+        const double *mp = sp + g * kPal;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            V[j] = mp[cb[j] & (kPalV - 1)];
+            U[j] = mp[kPalV + (cb[j] >> 3)];
+        }
+    } else {
         const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
         const double2 *pV = reinterpret_cast<const double2 *>(na.V + tile.node_base);
         const double2 *pU = reinterpret_cast<const double2 *>(na.U + tile.node_base);
@@ -97,67 +194,54 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
         }
     }
-    if constexpr (VAR == 3) {  // ablation build: stream T, V, U through and nothing else
-        if (active) {
-            double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
-#pragma unroll
-            for (int jp = 0; jp < M / 2; jp++)
-                pT[jp * Lk + lane] = make_double2(T[2 * jp] + 1e-9 * V[2 * jp] * U[2 * jp],
-                                                  T[2 * jp + 1] + 1e-9 * V[2 * jp + 1] * U[2 * jp + 1]);
-        }
-        return;
-    }
 
     const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
     const StepWeather w = weather[step];
-    const int S = sd.S;
-    const bool is_first = (seg == 0);
-    const bool is_last = (seg == k - 1);
     const int first_lane = g * k;
     const int last_lane = min(g * k + k - 1, kWave - 1);
-
-    // The first lane of a surface owns the front side, every other lane loads the back side
-    // (only the last lane's value is used). Tiles with k == 1 own both sides (second record below).
-    const bool my_back = !is_first;
-    const int sidx = (my_back ? S : 0) + d;
-    const SideConst c = sd.sc[sidx];
-    const SideDyn dy = sd.dyn[sidx];
     const int nn = c.kind_n >> 16;
-    const int jl = nn - 1 - (k - 1) * M;  // local index of the last node inside the last lane
+    const int jl = full ? (M - 1) : (nn - 1 - (k - 1) * M);  // local index of the last node inside the last lane
 
     auto pick_last = [&](const double (&x)[M]) {
-        double r = x[0];
+        double r = x[M - 1];
+        if (!full) {
 #pragma unroll
-        for (int j = 1; j < M; j++) r = (j == jl) ? x[j] : r;
+            for (int j = 0; j < M - 1; j++) r = (j == jl) ? x[j] : r;
+        }
         return r;
     };
 
     int bad = 0;
-    // One evaluation of calc_border_conditions for the side described by `cc` (surface.rs:596-717).
-    // Returns hs; air_t / rad_t / surf_t are what get_k_q and rad_hs need afterwards.
-    auto side = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, double T0v, double Tnv,
-                    double &air_t, double &rad_t, double &surf_t) {
-        air_t = boundary_temperature(cc, w, zone_T);
-        double rad_alt = air_t;
-        surf_t = back ? Tnv : T0v;
-        if (back && (cc.kind_n & 3) == KIND_AMBIENT) {
-            // back/Ambient takes t_front and the FRONT surface temperature (surface.rs:672-686)
+    // The part of calc_border_conditions (surface.rs:596-717) that does not change inside a sub-timestep:
+    // boundary temperature, radiant temperature, forced convection term, surface used for the quirk.
+    struct SideState {
+        double air_t, rad_t, forced, cos_eff, fix;
+        bool use_front_T;  // back/Ambient takes t_front and the FRONT surface temperature (surface.rs:672-686)
+    };
+    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec) {
+        SideState st;
+        const int kind = cc.kind_n & 3;
+        st.air_t = boundary_temperature(cc, w, zone_T);
+        st.rad_t = st.air_t;
+        st.use_front_T = false;
+        st.forced = 0.0;
+        st.cos_eff = cc.cos_eff;
+        if (kind == KIND_OUTDOOR) {
+            const bool windward = (cc.kind_n & 4) ? true : ((cc.nx * w.sin_wd + cc.ny * w.cos_wd) > 0.0);
+            st.forced = (windward ? 1.0 : 0.5) * (cc.forced * w.sqrt_ws);  // convection.rs:161-163
+            st.rad_t = dd.rad_t;                                           // surface.rs:647,692
+        } else if (back && kind == KIND_AMBIENT) {
             const SideConst fc = sd.sc[rec - S];
-            rad_alt = boundary_temperature(fc, w, zone_T);
-            surf_t = T0v;
+            st.rad_t = boundary_temperature(fc, w, zone_T);
+            st.use_front_T = true;
         }
-        double hs;
-        if constexpr (VAR >= 1) {  // ablation build: no boundary physics
-            hs = 5.0 + 1e-3 * surf_t;
-            rad_t = rad_alt;
-        } else {
-            eval_side(cc, w, air_t, rad_alt, dd.rad_t, surf_t, hs, rad_t, bad);
-        }
-        if (hs != hs) bad |= FLAG_NAN_HS;  // surface.rs:704-707
-        if (sd.hs_fix != nullptr) {        // debug overrides, surface.rs:708-714
-            const double fix = sd.hs_fix[rec];
-            if (fix == fix) hs = fix;
-        }
+        st.fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
+        return st;
+    };
+    auto conv = [&](const SideState &st, double surf_t) {
+        double hs = st.forced + tarp_natural(st.air_t, surf_t, st.cos_eff, bad);  // convection.rs:165-167
+        if (hs != hs) bad |= FLAG_NAN_HS;                                        // surface.rs:704-707
+        if (st.fix == st.fix) hs = st.fix;
         return hs;
     };
 
@@ -165,13 +249,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const double T0 = shfl_f64(T[0], first_lane);
     const double Tn = shfl_f64(pick_last(T), last_lane);
 
-    // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769),
-    // already multiplied by V = dt/C as rearrange_k does (surface.rs:168-187).
-    double GV[M], QP[M];
-#pragma unroll
-    for (int j = 0; j < M; j++) { GV[j] = 0.0; QP[j] = 0.0; }
-
-    // Conductance towards the previous lane's last node, and that node's temperature.
+    // Conductance towards the previous lane's last node.
     double UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
     if (is_first) UL = 0.0;
     unsigned int nm_passes = 0;
@@ -179,9 +257,12 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     double T_prev_last = 0.0;
     if constexpr (NM) T_prev_last = shfl_f64(T[M - 1], (lane + kWave - 1) & (kWave - 1));
 
-    auto add_face = [&](const SideConst &cc, const SideDyn &dd, bool back, double hs, double air_t, double rad_t,
-                        double surf_t) {
-        const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
+    // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769).
+    double hF = 0.0, qF = 0.0, hB = 0.0, qB = 0.0;
+    auto add_face = [&](const SideConst &cc, const SideDyn &dd, const SideState &st, bool back) {
+        const double surf_t = (back && !st.use_front_T) ? Tn : T0;
+        const double hs = conv(st, surf_t);
+        const double rhs = rad_hs(cc.emis, st.rad_t, surf_t);  // surface.rs:941-948
         const double sol = cc.alpha * dd.solar;
         if constexpr (NM) {
             // One-node no-mass chunk at this face (discretization.rs:658-697 for nnodes == 1):
@@ -210,7 +291,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 double old_err = 99999.;
                 int count = 0;
                 for (;;) {
-                    const double qf = air_t * hs + rhs * (rad_t - Tc);
+                    const double qf = st.air_t * hs + rhs * (st.rad_t - Tc);
                     const double q = ((back ? (nb + qf) : (qf + nb)) + sol) * -1.;
                     const double x = q / dg;
                     const double err = fabs(x - Tc);
@@ -232,101 +313,63 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 return;  // V == 0: the node takes no part in the RK4 below
             }
         }
-        if (!back) {
-            const double q = (air_t * hs + rhs * (rad_t - T[0])) + sol;
-            GV[0] += V[0] * hs;
-            QP[0] += V[0] * q;
-        } else {
-            const double q = (air_t * hs + rhs * (rad_t - pick_last(T))) + sol;
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                GV[j] += (j == jl) ? V[j] * hs : 0.0;
-                QP[j] += (j == jl) ? V[j] * q : 0.0;
-            }
-        }
+        const double tface = back ? pick_last(T) : T[0];
+        const double q = (st.air_t * hs + rhs * (st.rad_t - tface)) + sol;
+        if (!back) { hF = hs; qF = q; } else { hB = hs; qB = q; }
     };
 
-    double my_air, my_rad, my_surf;
-    {
-        const double hs = side(c, dy, my_back, sidx, T0, Tn, my_air, my_rad, my_surf);
-        if (is_first || is_last) add_face(c, dy, my_back, hs, my_air, my_rad, my_surf);
-    }
-    double b_air = 0.0;
+    const SideState my = prepare(c, dy, my_back, sidx);
+    if (is_first || is_last) add_face(c, dy, my, my_back);
+    SideState bs = my;
     if (k == 1) {  // single-lane surfaces: this lane is also the last one
-        const SideConst cb = sd.sc[S + d];
-        const SideDyn db = sd.dyn[S + d];
-        double b_rad, b_surf;
-        const double hs = side(cb, db, true, S + d, T0, Tn, b_air, b_rad, b_surf);
-        add_face(cb, db, true, hs, b_air, b_rad, b_surf);
+        const SideConst cb2 = sd.sc[S + d];
+        const SideDyn db2 = sd.dyn[S + d];
+        bs = prepare(cb2, db2, true, S + d);
+        add_face(cb2, db2, bs, true);
     }
 
-    // ---- RK4 on dT/dt = V (flux_right - flux_left - g T) + qp  (surface.rs:228-308) ----
-
-    auto rhs_eval = [&](const double (&x)[M], double (&kk)[M]) {
-        double xl = shfl_f64(x[M - 1], (lane + kWave - 1) & (kWave - 1));
-        double xr = shfl_f64(x[0], (lane + 1) & (kWave - 1));
-        if (is_first) xl = 0.0;  // never let another surface's value (possibly NaN) in
-        if (is_last) xr = 0.0;
-        double fprev = UL * (x[0] - xl);
-#pragma unroll
-        for (int j = 0; j < M; j++) {
-            const double xn = (j == M - 1) ? xr : x[(j + 1) % M];
-            const double f = U[j] * (xn - x[j]);
-            kk[j] = V[j] * (f - fprev) - GV[j] * x[j] + QP[j];
-            fprev = f;
-        }
-    };
-
-    double acc[M], aux[M], kk[M];
-    rhs_eval(T, kk);
-    if constexpr (VAR == 2) {  // ablation build: one Euler stage
-#pragma unroll
-        for (int j = 0; j < M; j++) T[j] = T[j] + kk[j];
+    // ---- RK4 (surface.rs:228-308) ----
+    double acc[M], aux[M];
+    if (full) {
+        rk_stage<M, true, 0>(T, T, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 1>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 2>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 3>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     } else {
-#pragma unroll
-        for (int j = 0; j < M; j++) { acc[j] = T[j] + kk[j] * (1.0 / 6.0); aux[j] = T[j] + 0.5 * kk[j]; }
-        rhs_eval(aux, kk);
-#pragma unroll
-        for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + 0.5 * kk[j]; }
-        rhs_eval(aux, kk);
-#pragma unroll
-        for (int j = 0; j < M; j++) { acc[j] += kk[j] * (1.0 / 3.0); aux[j] = T[j] + kk[j]; }
-        rhs_eval(aux, kk);
-#pragma unroll
-        for (int j = 0; j < M; j++) T[j] = acc[j] + kk[j] * (1.0 / 6.0);
+        rk_stage<M, false, 0>(T, T, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 1>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 2>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 3>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     }
 
     // ---- write back node temperatures (model.rs:145-147) ----
     if (active) {
         double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
 #pragma unroll
-        for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(T[2 * jp], T[2 * jp + 1]);
+        for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(aux[2 * jp], aux[2 * jp + 1]);
     }
 
     // ---- convection coefficients with the NEW temperatures + heat flows (model.rs:150-169) ----
-    const double T0n = shfl_f64(T[0], first_lane);
-    const double Tln = pick_last(T);
+    const double T0n = shfl_f64(aux[0], first_lane);
+    const double Tln = pick_last(aux);
     const double Tnn = shfl_f64(Tln, last_lane);
     {
-        double a_, r_, s_;
-        const double hs = side(c, dy, my_back, sidx, T0n, Tnn, a_, r_, s_);
-        const double face_t = my_back ? Tln : T[0];
+        const double surf_t = (my_back && !my.use_front_T) ? Tnn : T0n;
+        const double hs = conv(my, surf_t);
+        const double face_t = my_back ? Tln : aux[0];
         if (active && (is_first || is_last)) {
             SideOut o;
             o.hs = hs;
-            o.flow = (face_t - my_air) * hs;
+            o.flow = (face_t - my.air_t) * hs;
             sd.out[sidx] = o;
         }
     }
     if (k == 1) {
-        const SideConst cb = sd.sc[S + d];
-        const SideDyn db = sd.dyn[S + d];
-        double a_, r_, s_;
-        const double hs = side(cb, db, true, S + d, T0n, Tnn, a_, r_, s_);
+        const double hs = conv(bs, bs.use_front_T ? T0n : Tnn);
         if (active) {
             SideOut o;
             o.hs = hs;
-            o.flow = (Tln - b_air) * hs;
+            o.flow = (Tln - bs.air_t) * hs;
             sd.out[S + d] = o;
         }
     } else if (!(is_first || is_last)) {
@@ -786,7 +829,7 @@ k_nodes_fast(const FastTile *__restrict__ tiles, int n_tiles, double *__restrict
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave >= n_tiles) return;
     const FastTile tile = tiles[wave];
-    const int k = tile.k;
+    const int k = tile.k & 0xff;
     const int Lk = (kWave / k) * k;
     const int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
     const int seg = lane - g * k;
@@ -888,25 +931,27 @@ __global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
 // Launch wrappers (host).
 static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
 
-void launch_surfaces_fast(int M, int nm, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+void launch_surfaces_fast(int M, int nm, int pal, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
                           const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
     if (n_tiles <= 0) return;
     const dim3 grid(blocks_for_waves(n_tiles)), block(256);
-#define HEAT_LAUNCH_FAST(MM, NN, VV)                                                                              \
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, VV>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, step_ptr, \
-                       step_fixed, zone_T, flags, nomass_iters)
-    static const int var = getenv("HEAT_AMD_VARIANT") ? atoi(getenv("HEAT_AMD_VARIANT")) : 0;  // ablation builds (dev only)
-    if (M == 8 && nm == 0 && var == 1) { HEAT_LAUNCH_FAST(8, 0, 1); return; }
-    if (M == 8 && nm == 0 && var == 2) { HEAT_LAUNCH_FAST(8, 0, 2); return; }
-    if (M == 8 && nm == 0 && var == 3) { HEAT_LAUNCH_FAST(8, 0, 3); return; }
-    switch (M * 2 + (nm ? 1 : 0)) {
-    case 8: HEAT_LAUNCH_FAST(4, 0, 0); break;
-    case 9: HEAT_LAUNCH_FAST(4, 1, 0); break;
-    case 16: HEAT_LAUNCH_FAST(8, 0, 0); break;
-    case 17: HEAT_LAUNCH_FAST(8, 1, 0); break;
-    case 32: HEAT_LAUNCH_FAST(16, 0, 0); break;
-    default: HEAT_LAUNCH_FAST(16, 1, 0); break;
+#define HEAT_LAUNCH_FAST(MM, NN, PP)                                                                       \
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
+                       step_ptr, step_fixed, zone_T, flags, nomass_iters)
+    switch (M * 4 + (nm ? 2 : 0) + (pal ? 1 : 0)) {
+    case 16: HEAT_LAUNCH_FAST(4, 0, 0); break;
+    case 17: HEAT_LAUNCH_FAST(4, 0, 1); break;
+    case 18: HEAT_LAUNCH_FAST(4, 1, 0); break;
+    case 19: HEAT_LAUNCH_FAST(4, 1, 1); break;
+    case 32: HEAT_LAUNCH_FAST(8, 0, 0); break;
+    case 33: HEAT_LAUNCH_FAST(8, 0, 1); break;
+    case 34: HEAT_LAUNCH_FAST(8, 1, 0); break;
+    case 35: HEAT_LAUNCH_FAST(8, 1, 1); break;
+    case 64: HEAT_LAUNCH_FAST(16, 0, 0); break;
+    case 65: HEAT_LAUNCH_FAST(16, 0, 1); break;
+    case 66: HEAT_LAUNCH_FAST(16, 1, 0); break;
+    default: HEAT_LAUNCH_FAST(16, 1, 1); break;
     }
 #undef HEAT_LAUNCH_FAST
 }

@@ -33,7 +33,7 @@ enum : int { FLAG_NAN_HS = 1, FLAG_NAN_NOMASS = 2, FLAG_NAN_ZONE = 4, FLAG_UNREA
 struct FastTile {
     int64_t node_base;  // in doubles, into the unified node buffers
     int32_t surf_base;  // first device surface of the tile
-    int16_t k;          // lanes per surface
+    int16_t k;          // bits 0-7: lanes per surface; bit 8: every surface of the tile has n == k * M
     int16_t G;          // surfaces in this tile
 };
 
@@ -82,10 +82,20 @@ struct SideArrays {
 };
 
 // Unified per-node buffers (all groups).
+// Palette form of the per-node constants (fast classes with PAL = 1): a wall has only a handful of
+// distinct V = dt/mass and U values (one pair per layer, plus joints and end nodes), so each node
+// stores a one-byte class  c = vclass | uclass << 3  and each surface a palette of
+// kPalV V-values followed by kPalU U-values (entry 0 of both is 0.0: padding, no-mass, Back).
+constexpr int kPalV = 8;
+constexpr int kPalU = 4;
+constexpr int kPal = kPalV + kPalU;  // doubles per surface
+
 struct NodeArrays {
     double *T;               // node temperatures (state)
     const double *V;         // dt / mass for massive nodes, 0 for no-mass and padding
     const double *U;         // Solid u, 0 for Back/padding (cavity segments: 0, see cav)
+    const uint8_t *cls;      // PAL classes: class byte of node (lane l, j) at node_base + l * M + j
+    const double *pal;       // PAL classes: palette of device surface d at pal + d * kPal
     const double *alpha_f;   // general group only (same indexing), else nullptr
     const double *alpha_b;
     const int32_t *cav;      // general group only: cavity index or -1

@@ -142,6 +142,8 @@ typedef struct heat_batch_options {
      * heat_batch_step_surfaces -> all-gather of heat_batch_zone_partials -> heat_batch_step_zones. */
     int32_t n_ranks;
     int32_t rank;
+    int32_t no_palette;      /* 1: keep dt/mass and U as per-node arrays even where a palette would do */
+    int32_t reserved;
 } heat_batch_options;
 
 /* ≙ ThermalModel::new + allocate_memory: validates, packs and uploads the constants. */

@@ -47,12 +47,13 @@ def assert_state_close(md, ref, got):
     assert np.array_equal(ref[~owned], got[~owned])
 
 
-@pytest.mark.parametrize("npl", [0, 4, 8, 16])
-def test_config2_identical_massive_walls(oracle, npl):
+@pytest.mark.parametrize("npl,no_palette", [(0, False), (4, False), (8, False), (16, False), (0, True), (4, True),
+                                            (8, True), (16, True)])
+def test_config2_identical_massive_walls(oracle, npl, no_palette):
     # BASELINE config 2 at reduced S: identical 3-layer massive walls x 20 nodes, RK4 only
     md, st = mdl.uniform_massive(300, 20, Z=3, dt=90.0, identical=True, vertical=True)
     w = mdl.weather_series(60, 90.0)
-    ref, got, _, _, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
+    ref, got, _, _, counts = run_both(oracle, md, st, w, nodes_per_lane=npl, no_palette=no_palette)
     assert counts[3] + counts[4] == 0  # all on the fast path
     assert_state_close(md, ref, got)
 
@@ -230,7 +231,33 @@ def test_no_mass_facings_on_the_fast_path(oracle, n, npl, which):
     md["front_emissivity"] = md["front_emissivity"] * 0.2
     md["back_emissivity"] = md["back_emissivity"] * 0.2
     w = mdl.weather_series(20, 45.0)
-    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
-    assert counts[3] + counts[4] == 0, counts  # all on the fast path
-    assert iters == gpu_iters and iters > 0
+    for no_palette in (False, True):
+        ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, nodes_per_lane=npl, no_palette=no_palette)
+        assert counts[3] + counts[4] == 0, counts  # all on the fast path
+        assert iters == gpu_iters and iters > 0
+        assert_state_close(md, ref, got)
+
+
+@pytest.mark.parametrize("npl", [0, 4, 8])
+def test_many_layer_walls_fall_back_to_per_node_constants(oracle, npl):
+    """Walls with more distinct dt/mass or U values than the palette holds (8 / 4) keep per-node arrays;
+    walls within the limit use the palette; both in one batch, bitwise equal to the no-palette build."""
+    md, st = mdl.uniform_massive(400, 24, Z=4, dt=45.0, seed=77)
+    off = md["node_offset"]
+    rng = np.random.default_rng(5)
+    mass = md["mass"].copy()
+    u = md["uvalue"].copy()
+    for s_ in range(0, 400, 2):  # every other wall: 6 layers of 4 nodes with their own material
+        o = off[s_]
+        for layer in range(6):
+            f = rng.uniform(0.7, 1.3)
+            mass[o + 4 * layer:o + 4 * layer + 4] *= f
+            u[o + 4 * layer:o + 4 * layer + 4] *= rng.uniform(0.7, 1.3)
+        u[off[s_ + 1] - 1] = 0.0
+    md["mass"], md["uvalue"] = mass, u
+    w = mdl.weather_series(15, 45.0)
+    ref, got, _, _, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
+    assert counts[3] + counts[4] == 0
     assert_state_close(md, ref, got)
+    ref2, got2, *_ = run_both(oracle, md, st, w, nodes_per_lane=npl, no_palette=True)
+    assert np.array_equal(got, got2)
