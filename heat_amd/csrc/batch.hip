@@ -191,10 +191,17 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
     if (n == 2 && d->mass[o] < kMassThreshold && d->mass[o + 1] < kMassThreshold) return kGeneral;  // 2-node chunk
     int M = opt.nodes_per_lane;
     if (M == 0) {
-        // Same padding (to a multiple of 4) either way; M = 8 halves the per-surface boundary work.
-        // M = 16 is only taken on request: its working set spills at 256 VGPRs (profiles/README.md).
-        const int n4 = (n + 3) / 4 * 4;
-        M = (n4 % 8 == 0) ? 8 : 4;
+        // Nodes are padded to a multiple of M inside the last lane. Measured cost per padded node
+        // (1 M x 32 nodes, profiles/README.md): M = 16 : 8 : 4 = 1.00 : 1.05 : 1.16 — larger blocks amortise
+        // the per-surface boundary work over more nodes. Pick the cheapest.
+        const double w[3] = {1.16, 1.05, 1.00};
+        const int ms[3] = {4, 8, 16};
+        double best = 0.0;
+        for (int q = 0; q < 3; q++) {
+            const int padded = (n + ms[q] - 1) / ms[q] * ms[q];
+            const double cost = padded * w[q];
+            if (M == 0 || cost < best) { M = ms[q]; best = cost; }
+        }
     }
     const int k = (n + M - 1) / M;
     if (k > kWave) return kGeneral;

@@ -213,35 +213,31 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 
     int bad = 0;
     // The part of calc_border_conditions (surface.rs:596-717) that does not change inside a sub-timestep:
-    // boundary temperature, radiant temperature, forced convection term, surface used for the quirk.
-    struct SideState {
-        double air_t, rad_t, forced, cos_eff, fix;
-        bool use_front_T;  // back/Ambient takes t_front and the FRONT surface temperature (surface.rs:672-686)
-    };
-    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec) {
-        SideState st;
+    // boundary temperature, radiant temperature, forced convection term, and whether the side reads the
+    // FRONT surface temperature (back/Ambient takes t_front and the front temperature, surface.rs:672-686).
+    // Kept in plain scalars (a struct here ends up in scratch memory).
+    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, double &air_t, double &rad_t,
+                       double &forced, double &fix, bool &use_front_T) {
         const int kind = cc.kind_n & 3;
-        st.air_t = boundary_temperature(cc, w, zone_T);
-        st.rad_t = st.air_t;
-        st.use_front_T = false;
-        st.forced = 0.0;
-        st.cos_eff = cc.cos_eff;
+        air_t = boundary_temperature(cc, w, zone_T);
+        rad_t = air_t;
+        use_front_T = false;
+        forced = 0.0;
         if (kind == KIND_OUTDOOR) {
             const bool windward = (cc.kind_n & 4) ? true : ((cc.nx * w.sin_wd + cc.ny * w.cos_wd) > 0.0);
-            st.forced = (windward ? 1.0 : 0.5) * (cc.forced * w.sqrt_ws);  // convection.rs:161-163
-            st.rad_t = dd.rad_t;                                           // surface.rs:647,692
+            forced = (windward ? 1.0 : 0.5) * (cc.forced * w.sqrt_ws);  // convection.rs:161-163
+            rad_t = dd.rad_t;                                            // surface.rs:647,692
         } else if (back && kind == KIND_AMBIENT) {
             const SideConst fc = sd.sc[rec - S];
-            st.rad_t = boundary_temperature(fc, w, zone_T);
-            st.use_front_T = true;
+            rad_t = boundary_temperature(fc, w, zone_T);
+            use_front_T = true;
         }
-        st.fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
-        return st;
+        fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
     };
-    auto conv = [&](const SideState &st, double surf_t) {
-        double hs = st.forced + tarp_natural(st.air_t, surf_t, st.cos_eff, bad);  // convection.rs:165-167
-        if (hs != hs) bad |= FLAG_NAN_HS;                                        // surface.rs:704-707
-        if (st.fix == st.fix) hs = st.fix;
+    auto conv = [&](double air_t, double forced, double cos_eff, double fix, double surf_t) {
+        double hs = forced + tarp_natural(air_t, surf_t, cos_eff, bad);  // convection.rs:165-167
+        if (hs != hs) bad |= FLAG_NAN_HS;                                // surface.rs:704-707
+        if (fix == fix) hs = fix;
         return hs;
     };
 
@@ -259,10 +255,15 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 
     // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769).
     double hF = 0.0, qF = 0.0, hB = 0.0, qB = 0.0;
-    auto add_face = [&](const SideConst &cc, const SideDyn &dd, const SideState &st, bool back) {
-        const double surf_t = (back && !st.use_front_T) ? Tn : T0;
-        const double hs = conv(st, surf_t);
-        const double rhs = rad_hs(cc.emis, st.rad_t, surf_t);  // surface.rs:941-948
+    // add_face returns the face conductance and source through h_out / q_out (the caller files them
+    // under front or back with selects: storing through a runtime side index lands in scratch).
+    auto add_face = [&](const SideConst &cc, const SideDyn &dd, bool back, double air_t, double rad_t, double forced,
+                        double fix, bool use_front_T, double &h_out, double &q_out) {
+        h_out = 0.0;
+        q_out = 0.0;
+        const double surf_t = (back && !use_front_T) ? Tn : T0;
+        const double hs = conv(air_t, forced, cc.cos_eff, fix, surf_t);
+        const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
         const double sol = cc.alpha * dd.solar;
         if constexpr (NM) {
             // One-node no-mass chunk at this face (discretization.rs:658-697 for nnodes == 1):
@@ -291,7 +292,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 double old_err = 99999.;
                 int count = 0;
                 for (;;) {
-                    const double qf = st.air_t * hs + rhs * (st.rad_t - Tc);
+                    const double qf = air_t * hs + rhs * (rad_t - Tc);
                     const double q = ((back ? (nb + qf) : (qf + nb)) + sol) * -1.;
                     const double x = q / dg;
                     const double err = fabs(x - Tc);
@@ -314,18 +315,30 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             }
         }
         const double tface = back ? pick_last(T) : T[0];
-        const double q = (st.air_t * hs + rhs * (st.rad_t - tface)) + sol;
-        if (!back) { hF = hs; qF = q; } else { hB = hs; qB = q; }
+        h_out = hs;
+        q_out = (air_t * hs + rhs * (rad_t - tface)) + sol;
     };
 
-    const SideState my = prepare(c, dy, my_back, sidx);
-    if (is_first || is_last) add_face(c, dy, my, my_back);
-    SideState bs = my;
+    double my_air, my_rad, my_forced, my_fix;
+    bool my_useF;
+    prepare(c, dy, my_back, sidx, my_air, my_rad, my_forced, my_fix, my_useF);
+    if (is_first || is_last) {
+        double h_, q_;
+        add_face(c, dy, my_back, my_air, my_rad, my_forced, my_fix, my_useF, h_, q_);
+        hF = my_back ? 0.0 : h_;
+        qF = my_back ? 0.0 : q_;
+        hB = my_back ? h_ : 0.0;
+        qB = my_back ? q_ : 0.0;
+    }
+    double b_air = 0.0, b_forced = 0.0, b_fix = 0.0, b_cos = 0.0;
+    bool b_useF = false;
     if (k == 1) {  // single-lane surfaces: this lane is also the last one
         const SideConst cb2 = sd.sc[S + d];
         const SideDyn db2 = sd.dyn[S + d];
-        bs = prepare(cb2, db2, true, S + d);
-        add_face(cb2, db2, bs, true);
+        double b_rad;
+        prepare(cb2, db2, true, S + d, b_air, b_rad, b_forced, b_fix, b_useF);
+        b_cos = cb2.cos_eff;
+        add_face(cb2, db2, true, b_air, b_rad, b_forced, b_fix, b_useF, hB, qB);
     }
 
     // ---- RK4 (surface.rs:228-308) ----
@@ -354,22 +367,22 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const double Tln = pick_last(aux);
     const double Tnn = shfl_f64(Tln, last_lane);
     {
-        const double surf_t = (my_back && !my.use_front_T) ? Tnn : T0n;
-        const double hs = conv(my, surf_t);
+        const double surf_t = (my_back && !my_useF) ? Tnn : T0n;
+        const double hs = conv(my_air, my_forced, c.cos_eff, my_fix, surf_t);
         const double face_t = my_back ? Tln : aux[0];
         if (active && (is_first || is_last)) {
             SideOut o;
             o.hs = hs;
-            o.flow = (face_t - my.air_t) * hs;
+            o.flow = (face_t - my_air) * hs;
             sd.out[sidx] = o;
         }
     }
     if (k == 1) {
-        const double hs = conv(bs, bs.use_front_T ? T0n : Tnn);
+        const double hs = conv(b_air, b_forced, b_cos, b_fix, b_useF ? T0n : Tnn);
         if (active) {
             SideOut o;
             o.hs = hs;
-            o.flow = (Tln - bs.air_t) * hs;
+            o.flow = (Tln - b_air) * hs;
             sd.out[S + d] = o;
         }
     } else if (!(is_first || is_last)) {
