@@ -7,7 +7,7 @@ a ctypes binding (``HeatBatch``), the state-slot layout helper and the synthetic
 workloads used by tests and bench. There is no CPU fallback: creating a batch without the
 HIP library or without a GPU raises.
 """
-from .binding import HeatBatch, HeatError, Weather, lib_path, load_library, build_library  # noqa: F401
+from .binding import HeatBatch, HeatError, ModelBuilder, Weather, lib_path, load_library, build_library  # noqa: F401
 from . import modeldict  # noqa: F401
 
-__all__ = ["HeatBatch", "HeatError", "Weather", "lib_path", "load_library", "build_library", "modeldict"]
+__all__ = ["HeatBatch", "HeatError", "ModelBuilder", "Weather", "lib_path", "load_library", "build_library", "modeldict"]

@@ -65,7 +65,22 @@ class Options(C.Structure):
                 ("no_palette", C.c_int32), ("reserved", C.c_int32)]
 
 
-# Every symbol include/heat_amd.h declares: (name, restype, argtypes)
+class Layer(C.Structure):
+    """heat_layer (include/heat_amd_setup.h)"""
+    _fields_ = [("is_gas", C.c_int32), ("gas", C.c_int32), ("thickness", _d), ("conductivity", _d), ("density", _d),
+                ("specific_heat", _d), ("front_thermal_absorbtance", _d), ("back_thermal_absorbtance", _d),
+                ("solar_transmittance", _d), ("front_solar_absorbtance", _d), ("back_solar_absorbtance", _d)]
+
+
+class SurfaceIn(C.Structure):
+    """heat_surface_in (include/heat_amd_setup.h)"""
+    _fields_ = [("layers", C.POINTER(Layer)), ("n_layers", C.c_int32), ("is_fenestration", C.c_int32),
+                ("area", _d), ("perimeter", _d), ("normal", _d * 3), ("centroid_z", _d),
+                ("front_kind", C.c_int32), ("back_kind", C.c_int32), ("front_zone", C.c_int32),
+                ("back_zone", C.c_int32), ("front_ambient", _d), ("back_ambient", _d)]
+
+
+# Every symbol include/heat_amd.h and include/heat_amd_setup.h declare: (name, restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = [
     ("heat_batch_create", C.c_int, [C.POINTER(Desc), C.POINTER(_H)]),
@@ -92,6 +107,21 @@ SYMBOLS = [
     ("heat_batch_get_timing", C.c_int, [_H, _dp, _dp, _i64p]),
     ("heat_last_error", C.c_char_p, []),
     ("heat_amd_abi_version", C.c_int, []),
+    # include/heat_amd_setup.h
+    ("heat_discretize_construction", C.c_int, [C.c_int32, C.POINTER(Layer), _d, _d, _d, _i32p]),
+    ("heat_count_nodes", C.c_int32, [C.c_int32, _i32p]),
+    ("heat_build_segments", C.c_int, [C.c_int32, C.POINTER(Layer), _i32p, _d, _d, _dp, _dp, _i32p,
+                                      C.POINTER(Cavity), C.c_int32]),
+    ("heat_get_chunks", C.c_int, [C.c_int32, _dp, _i32p, _i32p, _i32p, _i32p]),
+    ("heat_glazing_alphas", C.c_int, [C.c_int32, _dp, _dp, _dp, _dp]),
+    ("heat_node_alphas", C.c_int, [C.c_int32, C.POINTER(Layer), _i32p, C.c_int32, _dp, _dp]),
+    ("heat_wind_speed_modifier", _d, [_d, C.c_int32]),
+    ("heat_model_builder_create", C.c_void_p, [C.c_int32, C.c_int32]),
+    ("heat_model_builder_destroy", None, [C.c_void_p]),
+    ("heat_model_builder_add_zone", C.c_int, [C.c_void_p, _d]),
+    ("heat_model_builder_add_surface", C.c_int, [C.c_void_p, C.POINTER(SurfaceIn)]),
+    ("heat_model_builder_finish", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(Desc)), C.POINTER(_dp), _i32p]),
+    ("heat_model_builder_surface_info", C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, C.c_int32]),
 ]
 
 _lib = None
@@ -302,3 +332,155 @@ class HeatBatch:
         c = (C.c_int64 * 5)()
         _check(self._L.heat_batch_class_counts(self._h, c))
         return list(c)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Setup-time half (include/heat_amd_setup.h)
+def make_layers(layers):
+    """list of dicts -> ctypes array of heat_layer. Keys: thickness, and either is_gas/gas or k, rho, cp;
+    optional front_thermal_abs, back_thermal_abs (0.84), tau (0), front_solar_abs, back_solar_abs (0.84) —
+    the defaults the reference applies when the substance does not define the property."""
+    arr = (Layer * len(layers))()
+    for i, L in enumerate(layers):
+        arr[i].is_gas = 1 if L.get("is_gas") else 0
+        arr[i].gas = int(L.get("gas", 0))
+        arr[i].thickness = float(L["thickness"])
+        arr[i].conductivity = float(L.get("k", 0.0))
+        arr[i].density = float(L.get("rho", 0.0))
+        arr[i].specific_heat = float(L.get("cp", 0.0))
+        arr[i].front_thermal_absorbtance = float(L.get("front_thermal_abs", 0.84))
+        arr[i].back_thermal_absorbtance = float(L.get("back_thermal_abs", 0.84))
+        arr[i].solar_transmittance = float(L.get("tau", 0.0))
+        arr[i].front_solar_absorbtance = float(L.get("front_solar_abs", 0.84))
+        arr[i].back_solar_absorbtance = float(L.get("back_solar_abs", 0.84))
+    return arr
+
+
+def discretize(layers, model_dt, max_dx, min_dt, height=1.0, angle=0.0):
+    """Discretization::new (reference src/discretization.rs:95-114) through the C ABI."""
+    L = load_library()
+    arr = make_layers(layers)
+    n_layers = len(layers)
+    n_el = (C.c_int32 * n_layers)()
+    sub = L.heat_discretize_construction(n_layers, arr, model_dt, max_dx, min_dt, n_el)
+    if sub < 0:
+        raise HeatError(sub, "heat_discretize_construction failed")
+    return build_segments(layers, list(n_el), height, angle, tstep_subdivision=sub)
+
+
+def build_segments(layers, n_elements, height=1.0, angle=0.0, tstep_subdivision=1):
+    L = load_library()
+    arr = make_layers(layers)
+    n_layers = len(layers)
+    n_el = (C.c_int32 * n_layers)(*n_elements)
+    n_nodes = L.heat_count_nodes(n_layers, n_el)
+    mass = np.zeros(n_nodes)
+    uval = np.zeros(n_nodes)
+    segc = np.zeros(n_nodes, dtype=np.int32)
+    cav = np.zeros(max(n_layers, 1), dtype=CAVITY_DTYPE)
+    nc = L.heat_build_segments(n_layers, arr, n_el, height, angle, mass.ctypes.data_as(_dp), uval.ctypes.data_as(_dp),
+                               segc.ctypes.data_as(_i32p), cav.ctypes.data_as(C.POINTER(Cavity)), 0)
+    if nc < 0:
+        raise HeatError(nc, "heat_build_segments failed")
+    fa = np.zeros(n_nodes)
+    ba = np.zeros(n_nodes)
+    rc = L.heat_node_alphas(n_layers, arr, n_el, n_nodes, fa.ctypes.data_as(_dp), ba.ctypes.data_as(_dp))
+    return dict(tstep_subdivision=tstep_subdivision, n_elements=list(n_elements), n_nodes=n_nodes, mass=mass,
+                uvalue=uval, seg_cavity=segc, cavities=cav[:nc].copy(), front_alpha=fa, back_alpha=ba, alpha_rc=rc)
+
+
+def get_chunks(mass):
+    L = load_library()
+    mass = np.ascontiguousarray(mass, dtype=np.float64)
+    n = len(mass)
+    nm, nn = C.c_int32(0), C.c_int32(0)
+    mc = (C.c_int32 * (2 * n + 2))()
+    nc = (C.c_int32 * (2 * n + 2))()
+    _check(L.heat_get_chunks(n, mass.ctypes.data_as(_dp), C.byref(nm), mc, C.byref(nn), nc))
+    return ([(mc[2 * i], mc[2 * i + 1]) for i in range(nm.value)],
+            [(nc[2 * i], nc[2 * i + 1]) for i in range(nn.value)])
+
+
+class ModelBuilder:
+    """ThermalModel::new (reference src/model.rs:215-354) through the C ABI: zones + surfaces with their
+    constructions in, the flattened model dict (heat_amd.modeldict) + initial SimulationState out."""
+
+    def __init__(self, n_per_hour, terrain=-1):
+        self._L = load_library()
+        self._h = self._L.heat_model_builder_create(n_per_hour, terrain)
+        if not self._h:
+            raise HeatError(-1, "heat_model_builder_create failed")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.heat_model_builder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_zone(self, volume):
+        return self._L.heat_model_builder_add_zone(self._h, float(volume))
+
+    def add_surface(self, layers, area, perimeter, normal, centroid_z, front_kind, back_kind, front_zone=0,
+                    back_zone=0, front_ambient=0.0, back_ambient=0.0, is_fenestration=False):
+        arr = make_layers(layers)
+        s = SurfaceIn()
+        s.layers = arr
+        s.n_layers = len(layers)
+        s.is_fenestration = 1 if is_fenestration else 0
+        s.area, s.perimeter, s.centroid_z = float(area), float(perimeter), float(centroid_z)
+        for i in range(3):
+            s.normal[i] = float(normal[i])
+        s.front_kind, s.back_kind, s.front_zone, s.back_zone = int(front_kind), int(back_kind), int(front_zone), int(back_zone)
+        s.front_ambient, s.back_ambient = float(front_ambient), float(back_ambient)
+        rc = self._L.heat_model_builder_add_surface(self._h, C.byref(s))
+        if rc < 0:
+            raise HeatError(rc, "heat_model_builder_add_surface failed")
+        return rc
+
+    def finish(self):
+        """Returns (model dict, initial state, dt_subdivisions)."""
+        pd = C.POINTER(Desc)()
+        ps = _dp()
+        nsub = C.c_int32(0)
+        rc = self._L.heat_model_builder_finish(self._h, C.byref(pd), C.byref(ps), C.byref(nsub))
+        if rc != 0:
+            raise HeatError(rc, "heat_model_builder_finish failed (the reference would panic or return Err here)")
+        d = pd.contents
+        S, Z, N = d.n_surfaces, d.n_zones, 0
+        off = np.ctypeslib.as_array(d.node_offset, shape=(S + 1,)).copy()
+        N = int(off[-1])
+
+        def arr(p, n):
+            return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0)
+
+        md = dict(n_surfaces=int(S), n_zones=int(Z), n_state=int(d.n_state), dt=float(d.dt), node_offset=off,
+                  front_hs_fix=None, back_hs_fix=None, seg_cavity=None, cavities=None)
+        for k in ("mass", "uvalue", "front_alpha", "back_alpha"):
+            md[k] = arr(getattr(d, k), N)
+        for k in _I32:
+            md[k] = arr(getattr(d, k), S).astype(np.int32)
+        for k in [x for x in _F64 if x not in ("mass", "uvalue", "front_alpha", "back_alpha", "zone_volume")]:
+            md[k] = arr(getattr(d, k), S)
+        for k in [x for x in _I64 if x not in ("node_offset", "zone_slot")]:
+            md[k] = arr(getattr(d, k), S).astype(np.int64)
+        md["zone_volume"] = arr(d.zone_volume, Z)
+        md["zone_slot"] = arr(d.zone_slot, Z).astype(np.int64)
+        if d.n_cavities:
+            md["seg_cavity"] = arr(d.seg_cavity, N).astype(np.int32)
+            cv = np.zeros(d.n_cavities, dtype=CAVITY_DTYPE)
+            C.memmove(cv.ctypes.data, d.cavities, cv.nbytes)
+            md["cavities"] = cv
+        state = np.ctypeslib.as_array(ps, shape=(int(d.n_state),)).copy()
+        return md, state, int(nsub.value)
+
+    def surface_info(self, i):
+        sub, nn = C.c_int32(0), C.c_int32(0)
+        el = (C.c_int32 * 64)()
+        n = self._L.heat_model_builder_surface_info(self._h, i, C.byref(sub), C.byref(nn), el, 64)
+        return dict(tstep_subdivision=sub.value, n_nodes=nn.value, n_elements=list(el[:n]))

@@ -261,3 +261,31 @@ def test_many_layer_walls_fall_back_to_per_node_constants(oracle, npl):
     assert_state_close(md, ref, got)
     ref2, got2, *_ = run_both(oracle, md, st, w, nodes_per_lane=npl, no_palette=True)
     assert np.array_equal(got, got2)
+
+
+def test_config1_end_to_end_through_the_product_setup_and_kernels(oracle):
+    """Constructions in, EnergyPlus-validated zone temperatures out, with no oracle code on the product side:
+    heat_model_builder_* (ThermalModel::new) -> heat_batch_create -> heat_batch_march per caller timestep."""
+    import os
+    from heat_amd import ModelBuilder
+    from test_energyplus_series import GOLD, march_series
+    mb = ModelBuilder(20)
+    z = mb.add_zone(600.)
+    poly = dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400., front_thermal_abs=0., back_thermal_abs=0.,
+                front_solar_abs=0., back_solar_abs=0.)
+    conc = dict(thickness=0.2, k=0.816, rho=1700., cp=800., front_thermal_abs=0., back_thermal_abs=0.,
+                front_solar_abs=0., back_solar_abs=0.)
+    mb.add_surface([poly, conc, poly], 60., 46., (0., -1., 0.), 1.5, mdl.OUTDOOR, mdl.SPACE, back_zone=z)
+    md, st, n_sub = mb.finish()
+    fx = dict(np.load(os.path.join(GOLD, "wall_mixed_no_ir_no_solar.npz")))
+    exp = fx["zone_t"]
+    ref_state = st.copy()
+    ref = march_series(oracle, md, ref_state, n_sub, fx, 0.0)
+    got_state = st.copy()
+    with HeatBatch(md) as b:
+        b.upload_state(got_state)
+        got = march_series(oracle, md, got_state, n_sub, fx, 0.0, march=lambda s, w: b.march(s, w))
+    assert np.allclose(got, ref, rtol=RTOL, atol=ATOL)
+    rmse = float(np.sqrt(np.mean((got[5001:] - exp[5001:]) ** 2)))
+    assert rmse < 0.1, rmse  # vs EnergyPlus, after the 5000-step warm-up of the reference's harness
+    mb.close()
