@@ -76,8 +76,9 @@ constexpr int kNumFast = 12;  // fast classes: (M, no-mass facings allowed, pale
 const int kFastM[kNumFast] = {4, 4, 4, 4, 8, 8, 8, 8, 16, 16, 16, 16};
 const int kFastNM[kNumFast] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1};
 const int kFastPAL[kNumFast] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
-constexpr int kSmall = kNumFast;        // all-no-mass surfaces of <= 4 nodes (general layout, register kernel)
-constexpr int kGeneral = kNumFast + 1;  // catch-all
+constexpr int kSmall = kNumFast;         // all-no-mass surfaces of <= 4 nodes (general layout, register kernel)
+constexpr int kSmallCav = kNumFast + 1;  // ... with a gas cavity (double glazing)
+constexpr int kGeneral = kNumFast + 2;   // catch-all
 
 }  // namespace
 
@@ -85,6 +86,11 @@ struct heat_batch {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // Independent surface classes run on side streams between a fork and a join event (captured into
+    // the sub-timestep graph as parallel branches).
+    static constexpr int kSideStreams = 3;
+    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr};
     int n_ranks = 1, rank = 0;
     bool use_graph = false;
 
@@ -98,7 +104,8 @@ struct heat_batch {
     int n_fast_tiles[kNumFast] = {};
     DevBuf<FastTile> d_fast_tiles[kNumFast];
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
-    int n_small_tiles = 0;
+    int n_small_tiles = 0;      // small tiles, cavity-free ones first
+    int n_small_plain_tiles = 0;
     size_t nm_count_base[kNumFast + 1] = {};
     DevBuf<GeneralTile> d_gen_tiles;
     int64_t gen_base = 0;     // first node slot of the general group
@@ -153,6 +160,11 @@ struct heat_batch {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (h_weather) (void)hipHostFree(h_weather);
         if (h_zone_ab) (void)hipHostFree(h_zone_ab);
+        for (int i = 0; i < kSideStreams; i++) {
+            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -175,7 +187,10 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
     if (n <= 4) {
         bool all_nomass = true;
         for (int i = 0; i < n; i++) all_nomass = all_nomass && (d->mass[o + i] < kMassThreshold);
-        if (all_nomass) return kSmall;
+        bool has_cav = false;
+        for (int i = 0; i < n; i++)
+            has_cav = has_cav || (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0);
+        if (all_nomass) return has_cav ? kSmallCav : kSmall;
     }
     if (n < 2) return kGeneral;
     int nm = 0;
@@ -312,7 +327,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         const int cls = classify(d, s, n, opt);
         const int M = cls < kNumFast ? kFastM[cls] : 0;
         placed[s] = Placed{s, n, cls, cls < kNumFast ? (n + M - 1) / M : 1};
-        b->class_counts[cls < kNumFast ? cls / 4 : (cls == kSmall ? 3 : 4)]++;
+        b->class_counts[cls < kNumFast ? cls / 4 : (cls < kGeneral ? 3 : 4)]++;
         if (cls < kNumFast && kFastPAL[cls]) b->n_palette++;
     }
     std::vector<int64_t> order(S);
@@ -368,7 +383,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             if (gen_tiles.empty()) b->gen_base = node_cursor;
             size_t end = pos;
             while (end < (size_t)S && end < pos + (size_t)kWave && placed[order[end]].cls == p0.cls) end++;
-            if (p0.cls == kSmall) b->n_small_tiles++;
+            if (p0.cls < kGeneral) b->n_small_tiles++;
+            if (p0.cls == kSmall) b->n_small_plain_tiles++;
             int n_max = 0;
             for (size_t q = pos; q < end; q++) n_max = std::max(n_max, placed[order[q]].n);
             GeneralTile t;
@@ -605,18 +621,60 @@ int select_device(heat_batch *b) {
 
 // iterate_surfaces for every group (model.rs:388-408)
 void enqueue_surfaces(heat_batch *b, int step_fixed) {
-    for (int c = 0; c < kNumFast; c++)
-        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na, b->sa,
-                             b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
-                             b->d_nomass_iters.p + b->nm_count_base[c], b->stream);
-    launch_surfaces_small(b->d_gen_tiles.p, b->n_small_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
-                          b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
-                          b->d_nomass_iters.p + b->nm_count_base[kNumFast], b->stream);
-    launch_surfaces_general(b->d_gen_tiles.p + b->n_small_tiles, b->n_gen_tiles - b->n_small_tiles, b->na,
-                            b->gen_base, b->sa, b->d_cavs.p, b->d_scratch.p, b->d_weather.p, b->d_step.p,
-                            step_fixed, b->d_zone_T.p, b->d_flags.p,
-                            b->d_nomass_iters.p + b->nm_count_base[kNumFast] + (size_t)b->n_small_tiles * kWave,
-                            b->stream);
+    // The classes are independent (model.rs:102-180: surfaces never read what another surface wrote in the
+    // same sub-timestep): spread them over the batch's stream and its side streams so that one class's
+    // tail overlaps the next class's head.
+    int n_launch = 0;
+    for (int c = 0; c < kNumFast; c++) n_launch += b->n_fast_tiles[c] > 0;
+    n_launch += b->n_small_plain_tiles > 0;
+    n_launch += b->n_small_tiles > b->n_small_plain_tiles;
+    n_launch += b->n_gen_tiles > b->n_small_tiles;
+    const bool fork = n_launch > 1 && b->side[0] != nullptr;
+    int used = 0, slot = 0;
+    auto next_stream = [&]() -> hipStream_t {
+        if (!fork) return b->stream;
+        const int s = slot++ % (heat_batch::kSideStreams + 1);
+        if (s == 0) return b->stream;
+        used |= 1 << (s - 1);
+        return b->side[s - 1];
+    };
+    if (fork) {
+        (void)hipEventRecord(b->ev_fork, b->stream);
+        for (int i = 0; i < heat_batch::kSideStreams; i++) (void)hipStreamWaitEvent(b->side[i], b->ev_fork, 0);
+    }
+    // biggest classes first
+    int order[kNumFast];
+    for (int c = 0; c < kNumFast; c++) order[c] = c;
+    std::sort(order, order + kNumFast, [&](int x, int y) { return b->n_fast_tiles[x] > b->n_fast_tiles[y]; });
+    for (int q = 0; q < kNumFast; q++) {
+        const int c = order[q];
+        if (b->n_fast_tiles[c] <= 0) continue;
+        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
+                             b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
+                             b->d_nomass_iters.p + b->nm_count_base[c], next_stream());
+    }
+    unsigned long long *cnt = b->d_nomass_iters.p + b->nm_count_base[kNumFast];
+    if (b->n_small_plain_tiles > 0)
+        launch_surfaces_small(0, b->d_gen_tiles.p, b->n_small_plain_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
+                              b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p, cnt,
+                              next_stream());
+    if (b->n_small_tiles > b->n_small_plain_tiles)
+        launch_surfaces_small(1, b->d_gen_tiles.p + b->n_small_plain_tiles, b->n_small_tiles - b->n_small_plain_tiles,
+                              b->na, b->gen_base, b->sa, b->d_cavs.p, b->d_weather.p, b->d_step.p, step_fixed,
+                              b->d_zone_T.p, b->d_flags.p, cnt + (size_t)b->n_small_plain_tiles * kWave,
+                              next_stream());
+    if (b->n_gen_tiles > b->n_small_tiles)
+        launch_surfaces_general(b->d_gen_tiles.p + b->n_small_tiles, b->n_gen_tiles - b->n_small_tiles, b->na,
+                                b->gen_base, b->sa, b->d_cavs.p, b->d_scratch.p, b->d_weather.p, b->d_step.p,
+                                step_fixed, b->d_zone_T.p, b->d_flags.p, cnt + (size_t)b->n_small_tiles * kWave,
+                                next_stream());
+    if (fork) {
+        for (int i = 0; i < heat_batch::kSideStreams; i++) {
+            if (!(used & (1 << i))) continue;
+            (void)hipEventRecord(b->ev_join[i], b->side[i]);
+            (void)hipStreamWaitEvent(b->stream, b->ev_join[i], 0);
+        }
+    }
 }
 
 void enqueue_zones(heat_batch *b, int mode) {
@@ -686,6 +744,15 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
             if (e != hipSuccess) rc = fail(HEAT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
             b->own_stream = true;
         }
+    }
+    if (!rc) {
+        for (int i = 0; i < heat_batch::kSideStreams && !rc; i++) {
+            if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess)
+                rc = fail(HEAT_E_DEVICE, "side stream creation failed");
+        }
+        if (!rc && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess)
+            rc = fail(HEAT_E_DEVICE, "event creation failed");
     }
     if (!rc) rc = build(b, desc, opt);
     if (rc) {

@@ -620,6 +620,7 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
 // cavity): one lane per surface, the whole chunk (0, n) in registers. Same layout as the general
 // group, reference operation order (march_nomass, surface.rs:790-898), no FMA contraction.
 #pragma clang fp contract(off)
+template <int CAV>
 __global__ void __launch_bounds__(256)
 k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
                  SideArrays sd, const CavityDev *__restrict__ cavs,
@@ -654,7 +655,7 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
         const bool v = j < nn;
         T[j] = v ? Tg[(int64_t)j * kWave] : 0.0;
         Us[j] = v ? Ug[(int64_t)j * kWave] : 0.0;
-        cav[j] = v ? na.cav[gofs + (int64_t)j * kWave] : -1;
+        cav[j] = (CAV && v) ? na.cav[gofs + (int64_t)j * kWave] : -1;
         // surface.rs:930-931
         double sj = v ? na.alpha_f[gofs + (int64_t)j * kWave] * df.solar : 0.0;
         sj += v ? na.alpha_b[gofs + (int64_t)j * kWave] * db.solar : 0.0;
@@ -697,7 +698,9 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
         for (int j = 0; j < NS - 1; j++) {
             if (j < nn - 1) {
                 double u = Us[j];
-                if (cav[j] >= 0) u = cavity_u_value(cavs[cav[j]], T[j], T[j + 1], bad);
+                if constexpr (CAV) {
+                    if (cav[j] >= 0) u = cavity_u_value(cavs[cav[j]], T[j], T[j + 1], bad);
+                }
                 dg[j] += -u;
                 dg[j + 1] = dg[j + 1] - u;
                 up[j] = up[j] + u;
@@ -978,13 +981,17 @@ void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeAr
                        gen_base, sa, cavs, scratch, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
 }
 
-void launch_surfaces_small(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
-                           const SideArrays &sa, const CavityDev *cavs, const StepWeather *weather,
-                           const int *step_ptr, int step_fixed, const double *zone_T, int *flags,
-                           unsigned long long *nomass_iters, hipStream_t st) {
+void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_tiles, const NodeArrays &na,
+                           int64_t gen_base, const SideArrays &sa, const CavityDev *cavs,
+                           const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
+                           int *flags, unsigned long long *nomass_iters, hipStream_t st) {
     if (n_tiles <= 0) return;
-    hipLaunchKernelGGL(k_surfaces_small, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, na,
-                       gen_base, sa, cavs, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
+    if (with_cavities)
+        hipLaunchKernelGGL(k_surfaces_small<1>, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, na,
+                           gen_base, sa, cavs, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
+    else
+        hipLaunchKernelGGL(k_surfaces_small<0>, dim3(blocks_for_waves(n_tiles)), dim3(256), 0, st, tiles, n_tiles, na,
+                           gen_base, sa, cavs, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
 }
 
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,

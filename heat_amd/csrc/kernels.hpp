@@ -17,10 +17,10 @@ void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeAr
                              const SideArrays &sa, const CavityDev *cavs, double *scratch,
                              const StepWeather *weather, const int *step_ptr, int step_fixed,
                              const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st);
-void launch_surfaces_small(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
-                           const SideArrays &sa, const CavityDev *cavs, const StepWeather *weather,
-                           const int *step_ptr, int step_fixed, const double *zone_T, int *flags,
-                           unsigned long long *nomass_iters, hipStream_t st);
+void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_tiles, const NodeArrays &na,
+                           int64_t gen_base, const SideArrays &sa, const CavityDev *cavs,
+                           const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
+                           int *flags, unsigned long long *nomass_iters, hipStream_t st);
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, hipStream_t st);
