@@ -72,10 +72,13 @@ struct DevBuf {
 
 constexpr int kMaxNodesGeneral = 4096;
 constexpr int kScratchArrays = 7;
-constexpr int kNumFast = 12;  // fast classes: (M, no-mass facings allowed, palette constants)
-const int kFastM[kNumFast] = {4, 4, 4, 4, 8, 8, 8, 8, 16, 16, 16, 16};
-const int kFastNM[kNumFast] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1};
-const int kFastPAL[kNumFast] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
+// fast classes: index = mi * 6 + nm * 3 + v;  M = 4 << mi;  nm: no-mass facings allowed;
+// v = 0 per-node arrays, 1 palette constants, 2 palette + gas cavities between massive nodes
+constexpr int kNumFast = 18;
+const int kFastM[kNumFast] = {4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 16, 16, 16, 16, 16, 16};
+const int kFastNM[kNumFast] = {0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1};
+const int kFastPAL[kNumFast] = {0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1};
+const int kFastCAV[kNumFast] = {0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
 constexpr int kSmall = kNumFast;         // all-no-mass surfaces of <= 4 nodes (general layout, register kernel)
 constexpr int kSmallCav = kNumFast + 1;  // ... with a gas cavity (double glazing)
 constexpr int kGeneral = kNumFast + 2;   // catch-all
@@ -113,6 +116,7 @@ struct heat_batch {
 
     DevBuf<double> d_T, d_V, d_U, d_alpha_f, d_alpha_b, d_mass, d_scratch;
     DevBuf<int32_t> d_cav_idx;
+    DevBuf<int32_t> d_cavref;  // CAV fast classes: 4 ints per device surface
     DevBuf<uint8_t> d_cls;   // palette class bytes (PAL fast classes)
     DevBuf<double> d_pal;    // palettes, kPal doubles per device surface
     DevBuf<CavityDev> d_cavs;
@@ -193,13 +197,19 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
         if (all_nomass) return has_cav ? kSmallCav : kSmall;
     }
     if (n < 2) return kGeneral;
-    int nm = 0;
+    int nm = 0, ncav = 0;
+    auto is_cav = [&](int i) { return d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0; };
     for (int i = 0; i < n; i++) {
         if (d->mass[o + i] < kMassThreshold) {
             if (i != 0 && i != n - 1) return kGeneral;                        // no-mass node inside
             nm = 1;
         }
-        if (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0) return kGeneral;  // gas cavity
+        if (is_cav(i)) {
+            // a cavity on the fast path sits between two massive nodes (its conductance is then needed
+            // once per sub-timestep, not once per pass of a no-mass loop)
+            if (i + 1 >= n || d->mass[o + i] < kMassThreshold || d->mass[o + i + 1] < kMassThreshold) return kGeneral;
+            if (++ncav > 2) return kGeneral;
+        }
         if (i > 0 && d->front_alpha[o + i] != 0.0) return kGeneral;           // solar absorbed inside
         if (i < n - 1 && d->back_alpha[o + i] != 0.0) return kGeneral;
     }
@@ -230,7 +240,7 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
         for (int i = 0; i < n && pal; i++) {
             const double mass = d->mass[o + i];
             const double v = (mass >= kMassThreshold) ? d->dt / mass : 0.0;
-            const double u = d->uvalue[o + i];
+            const double u = is_cav(i) ? 0.0 : d->uvalue[o + i];
             int f = -1;
             for (int q = 0; q < nv; q++) if (vv[q] == v) f = q;
             if (f < 0) { if (nv == kPalV) pal = 0; else vv[nv++] = v; }
@@ -239,7 +249,8 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
             if (f < 0) { if (nu == kPalU) pal = 0; else uu[nu++] = u; }
         }
     }
-    return (M == 4 ? 0 : (M == 8 ? 4 : 8)) + nm * 2 + pal;
+    if (ncav > 0 && !pal) return kGeneral;  // the cavity variant exists in palette form only
+    return (M == 4 ? 0 : (M == 8 ? 6 : 12)) + nm * 3 + (ncav > 0 ? 2 : pal);
 }
 
 int check_desc(const heat_batch_desc *d) {
@@ -327,7 +338,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         const int cls = classify(d, s, n, opt);
         const int M = cls < kNumFast ? kFastM[cls] : 0;
         placed[s] = Placed{s, n, cls, cls < kNumFast ? (n + M - 1) / M : 1};
-        b->class_counts[cls < kNumFast ? cls / 4 : (cls < kGeneral ? 3 : 4)]++;
+        b->class_counts[cls < kNumFast ? cls / 6 : (cls < kGeneral ? 3 : 4)]++;
         if (cls < kNumFast && kFastPAL[cls]) b->n_palette++;
     }
     std::vector<int64_t> order(S);
@@ -461,6 +472,28 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         nodeN_index[s] = node_index(dd, n - 1);
     }
 
+    // ---- cavity references of the CAV fast classes ----
+    std::vector<int32_t> hCavRef;
+    {
+        bool any = false;
+        for (int64_t s = 0; s < S; s++) any = any || (placed[s].cls < kNumFast && kFastCAV[placed[s].cls]);
+        if (any) {
+            hCavRef.assign((size_t)4 * S, -1);
+            for (int64_t dd = 0; dd < S; dd++) {
+                const int64_t s = orig_of[dd];
+                if (!(placed[s].cls < kNumFast && kFastCAV[placed[s].cls])) continue;
+                const int64_t o = d->node_offset[s];
+                int r = 0;
+                for (int i = 0; i < placed[s].n && r < 2; i++)
+                    if (d->seg_cavity[o + i] >= 0) {
+                        hCavRef[4 * dd + 2 * r] = i;
+                        hCavRef[4 * dd + 2 * r + 1] = d->seg_cavity[o + i];
+                        r++;
+                    }
+            }
+        }
+    }
+
     // ---- per-side records (device order) ----
     std::vector<int32_t> hMeta(S);
     std::vector<SideConst> hSide(2 * S);
@@ -547,6 +580,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_alpha_b.upload(hAb));
     HIP_TRY(b->d_mass.upload(hMass));
     HIP_TRY(b->d_cav_idx.upload(hCav));
+    HIP_TRY(b->d_cavref.upload(hCavRef));
     HIP_TRY(b->d_cls.upload(hCls));
     HIP_TRY(b->d_pal.upload(hPal));
     HIP_TRY(b->d_scratch.alloc(scratch_cursor));
@@ -606,6 +640,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     NodeArrays &na = b->na;
     na.T = b->d_T.p; na.V = b->d_V.p; na.U = b->d_U.p;
     na.cls = b->d_cls.p; na.pal = b->d_pal.p;
+    na.cavref = b->d_cavref.p; na.cavs = b->d_cavs.p;
     na.alpha_f = b->d_alpha_f.p; na.alpha_b = b->d_alpha_b.p; na.cav = b->d_cav_idx.p; na.mass = b->d_mass.p;
     SlotArrays &sl = b->sl;
     const int64_t *sp = b->d_slots.p;
@@ -649,7 +684,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
     for (int q = 0; q < kNumFast; q++) {
         const int c = order[q];
         if (b->n_fast_tiles[c] <= 0) continue;
-        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
+        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], kFastCAV[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
                              b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
                              b->d_nomass_iters.p + b->nm_count_base[c], next_stream());
     }

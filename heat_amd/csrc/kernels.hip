@@ -104,7 +104,10 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
 // (march_nomass, surface.rs:790-898) in the face lane before the massive nodes march.
 // PAL = 1: V and U come from the surface's palette (staged in LDS) through one class byte per node
 // instead of two doubles per node (layout.hpp).
-template <int M, int NM, int PAL>
+// CAV = 1: up to two gas cavities between massive nodes; their conductance (Cavity::u_value, cavity.rs:59-69)
+// is evaluated once per sub-timestep from the temperatures the massive chunk starts from, as get_k_q does
+// (discretization.rs:634-639), and frozen over the four RK stages (surface.rs:268-293).
+template <int M, int NM, int PAL, int CAV>
 __global__ void __launch_bounds__(256)
 k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
@@ -339,6 +342,30 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         prepare(cb2, db2, true, S + d, b_air, b_rad, b_forced, b_fix, b_useF);
         b_cos = cb2.cos_eff;
         add_face(cb2, db2, true, b_air, b_rad, b_forced, b_fix, b_useF, hB, qB);
+    }
+
+    if constexpr (CAV) {
+        const double T_next_first = shfl_f64(T[0], (lane + 1) & (kWave - 1));
+        const int4 ref = reinterpret_cast<const int4 *>(na.cavref)[d];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int node = r ? ref.z : ref.x;
+            const int cidx = r ? ref.w : ref.y;
+            const int jc = node - seg * M;
+            if (active && cidx >= 0 && jc >= 0 && jc < M) {
+                double ta = T[0], tb = T_next_first;
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    ta = (j == jc) ? T[j] : ta;
+                    if (j + 1 < M) tb = (j == jc) ? T[j + 1] : tb;
+                }
+                const double u = cavity_u_value(na.cavs[cidx], ta, tb, bad);
+#pragma unroll
+                for (int j = 0; j < M; j++) U[j] = (j == jc) ? u : U[j];
+            }
+        }
+        UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
+        if (is_first) UL = 0.0;
     }
 
     // ---- RK4 (surface.rs:228-308) ----
@@ -947,28 +974,25 @@ __global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
 // Launch wrappers (host).
 static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
 
-void launch_surfaces_fast(int M, int nm, int pal, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+void launch_surfaces_fast(int M, int nm, int pal, int cav, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
                           const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
     if (n_tiles <= 0) return;
     const dim3 grid(blocks_for_waves(n_tiles)), block(256);
-#define HEAT_LAUNCH_FAST(MM, NN, PP)                                                                       \
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
+#define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                       \
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
                        step_ptr, step_fixed, zone_T, flags, nomass_iters)
-    switch (M * 4 + (nm ? 2 : 0) + (pal ? 1 : 0)) {
-    case 16: HEAT_LAUNCH_FAST(4, 0, 0); break;
-    case 17: HEAT_LAUNCH_FAST(4, 0, 1); break;
-    case 18: HEAT_LAUNCH_FAST(4, 1, 0); break;
-    case 19: HEAT_LAUNCH_FAST(4, 1, 1); break;
-    case 32: HEAT_LAUNCH_FAST(8, 0, 0); break;
-    case 33: HEAT_LAUNCH_FAST(8, 0, 1); break;
-    case 34: HEAT_LAUNCH_FAST(8, 1, 0); break;
-    case 35: HEAT_LAUNCH_FAST(8, 1, 1); break;
-    case 64: HEAT_LAUNCH_FAST(16, 0, 0); break;
-    case 65: HEAT_LAUNCH_FAST(16, 0, 1); break;
-    case 66: HEAT_LAUNCH_FAST(16, 1, 0); break;
-    default: HEAT_LAUNCH_FAST(16, 1, 1); break;
+#define HEAT_LAUNCH_M(MM)                                     \
+    switch ((nm ? 3 : 0) + (cav ? 2 : (pal ? 1 : 0))) {       \
+    case 0: HEAT_LAUNCH_FAST(MM, 0, 0, 0); break;             \
+    case 1: HEAT_LAUNCH_FAST(MM, 0, 1, 0); break;             \
+    case 2: HEAT_LAUNCH_FAST(MM, 0, 1, 1); break;             \
+    case 3: HEAT_LAUNCH_FAST(MM, 1, 0, 0); break;             \
+    case 4: HEAT_LAUNCH_FAST(MM, 1, 1, 0); break;             \
+    default: HEAT_LAUNCH_FAST(MM, 1, 1, 1); break;            \
     }
+    if (M == 4) { HEAT_LAUNCH_M(4) } else if (M == 8) { HEAT_LAUNCH_M(8) } else { HEAT_LAUNCH_M(16) }
+#undef HEAT_LAUNCH_M
 #undef HEAT_LAUNCH_FAST
 }
 

@@ -96,6 +96,9 @@ struct NodeArrays {
     const double *U;         // Solid u, 0 for Back/padding (cavity segments: 0, see cav)
     const uint8_t *cls;      // PAL classes: class byte of node (lane l, j) at node_base + l * M + j
     const double *pal;       // PAL classes: palette of device surface d at pal + d * kPal
+    const int32_t *cavref;   // CAV classes: per device surface {node, cavity, node, cavity}: up to two gas
+                             // cavities between massive nodes (segment node -> node+1), -1 = none
+    const struct CavityDev *cavs;
     const double *alpha_f;   // general group only (same indexing), else nullptr
     const double *alpha_b;
     const int32_t *cav;      // general group only: cavity index or -1
