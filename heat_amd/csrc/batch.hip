@@ -677,6 +677,13 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
         (void)hipEventRecord(b->ev_fork, b->stream);
         for (int i = 0; i < heat_batch::kSideStreams; i++) (void)hipStreamWaitEvent(b->side[i], b->ev_fork, 0);
     }
+    // work of each class in node slots, to size the persistent grids
+    double work[kNumFast], total_work = 0.0;
+    for (int c = 0; c < kNumFast; c++) {
+        work[c] = (double)b->n_fast_tiles[c] * kFastM[c];
+        total_work += work[c];
+    }
+    total_work += 2.0 * b->n_gen_tiles;  // small / general tiles: a few nodes per lane
     // biggest classes first
     int order[kNumFast];
     for (int c = 0; c < kNumFast; c++) order[c] = c;
@@ -684,7 +691,8 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
     for (int q = 0; q < kNumFast; q++) {
         const int c = order[q];
         if (b->n_fast_tiles[c] <= 0) continue;
-        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], kFastCAV[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
+        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], kFastCAV[c], work[c] / total_work,
+                             b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
                              b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
                              b->d_nomass_iters.p + b->nm_count_base[c], next_stream());
     }

@@ -14,6 +14,9 @@
 // No MFMA anywhere: this is an HBM-bound f64 stencil.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
 #include "layout.hpp"
@@ -114,9 +117,13 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 const double *__restrict__ zone_T, int *__restrict__ flags,
                 unsigned long long *__restrict__ nomass_iters) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= n_tiles) return;
-
+    const int wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const StepWeather w = weather[step];
+    // Persistent waves: each walks the tile list with a grid stride, so the write-back of one tile (a wave
+    // cannot retire before its stores are acknowledged) overlaps the loads of the next.
+    for (int wave = wave0; wave < n_tiles; wave += n_waves) {
     const FastTile tile = tiles[wave];
     const int k = tile.k & 0xff;
     const bool full = (tile.k & 0x100) != 0;
@@ -198,8 +205,6 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         }
     }
 
-    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
-    const StepWeather w = weather[step];
     const int first_lane = g * k;
     const int last_lane = min(g * k + k - 1, kWave - 1);
     const int nn = c.kind_n >> 16;
@@ -423,6 +428,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
         if (lane == 0 && tot) nomass_iters[wave] += tot;
     }
+    }  // tile loop
 }
 
 // ---------------------------------------------------------------------------
@@ -974,11 +980,27 @@ __global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
 // Launch wrappers (host).
 static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
 
-void launch_surfaces_fast(int M, int nm, int pal, int cav, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
+                          const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
                           const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
     if (n_tiles <= 0) return;
-    const dim3 grid(blocks_for_waves(n_tiles)), block(256);
+    // persistent grid: as many 4-wave blocks as the chip holds at this kernel's occupancy (waves per SIMD by
+    // VGPR count: M = 4 -> 5, M = 8 -> 3, M = 16 -> 2), capped by the number of tiles
+    static const int n_cu = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    static const int tune = getenv("HEAT_AMD_PERSIST") ? atoi(getenv("HEAT_AMD_PERSIST")) : 1;
+    const int blocks_per_cu = (M == 4 ? 5 : (M == 8 ? 3 : 2)) * tune;
+    const int full_grid = blocks_for_waves(n_tiles);
+    // A class that has the chip to itself runs persistently; classes that run side by side on several streams
+    // launch one wave per tile and let the dispatcher interleave them (measured: dividing the chip between
+    // persistent grids by work share was 1.7x slower on the ragged config).
+    const bool persistent = tune > 0 && grid_share > 0.999;
+    const dim3 grid(persistent ? std::min(full_grid, n_cu * blocks_per_cu) : full_grid), block(256);
 #define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                       \
     hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
                        step_ptr, step_fixed, zone_T, flags, nomass_iters)

@@ -10,7 +10,8 @@ struct SlotArrays {
     const int64_t *hs_f, *hs_b, *flow_f, *flow_b, *solar_f, *solar_b, *ir_f, *ir_b;
 };
 
-void launch_surfaces_fast(int M, int nm, int pal, int cav, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
+                          const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
                           const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st);
 void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
