@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-palette", action="store_true", help="keep dt/mass and U as per-node arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,12 +133,16 @@ def main():
     weather_w = mdl.weather_series(max(W, 1), dt)
     weather_k = mdl.weather_series(K, dt, t0=dt * W)
 
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch
         import torch.distributed as dist
         from heat_amd.sharded import ShardedMarch
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         sm = ShardedMarch(md, rank, world, device_index=local_rank, nodes_per_lane=args.nodes_per_lane,
                           no_palette=args.no_palette)
         batch = sm.batch
@@ -145,6 +151,7 @@ def main():
         def barrier():
             dist.barrier()
             torch.cuda.synchronize()
+            batch.synchronize()  # reports device-side numerical flags
 
         run = sm.march_resident
     else:
@@ -168,7 +175,7 @@ def main():
     surf_us, substep_us, n_samples = batch.get_timing()
     batch.set_timing(False)
 
-    if world > 1:
+    if sharded:
         import torch
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -201,7 +208,7 @@ def main():
             "zones_per_gpu": args.zones_per_gpu, "dt_s": dt,
             "kernel_classes[M4,M8,M16,small,general]": counts,
             "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep all-gather of zone partials" % world
-            if world > 1 else "single GPU",
+            if sharded else "single GPU",
         },
     }
     if n_samples > 0:
@@ -216,7 +223,7 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.nodes, dt, seed)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         sm.close()
         dist.destroy_process_group()

@@ -97,6 +97,8 @@ SYMBOLS = [
     ("heat_batch_step_zones", C.c_int, [_H, C.c_void_p, C.c_int32]),
     ("heat_batch_zone_partials", C.c_void_p, [_H]),
     ("heat_batch_use_partials", C.c_int, [_H, C.c_void_p]),
+    ("heat_batch_touched_zones", C.c_int, [_H, C.POINTER(C.c_uint8)]),
+    ("heat_batch_set_shared_zones", C.c_int, [_H, _i32p, C.c_int32]),
     ("heat_batch_n_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_nodes", C.c_int64, [_H]),
     ("heat_batch_n_zones", C.c_int64, [_H]),
@@ -308,6 +310,15 @@ class HeatBatch:
 
     def use_partials(self, dev_ptr):
         _check(self._L.heat_batch_use_partials(self._h, dev_ptr))
+
+    def touched_zones(self):
+        m = np.zeros(self.n_zones, dtype=np.uint8)
+        _check(self._L.heat_batch_touched_zones(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return m
+
+    def set_shared_zones(self, shared_zone):
+        sz = np.ascontiguousarray(shared_zone, dtype=np.int32)
+        _check(self._L.heat_batch_set_shared_zones(self._h, sz.ctypes.data_as(_i32p), len(sz)))
 
     def set_timing(self, enabled):
         _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))

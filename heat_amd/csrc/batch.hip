@@ -131,6 +131,11 @@ struct heat_batch {
     DevBuf<ZoneEntry> d_zone_entries;
     DevBuf<double> d_zone_vol, d_zone_T, d_zone_a0, d_zone_b0, d_partial;
     double *partial_ptr = nullptr;  // where step_surfaces writes (a, b): d_partial or caller memory
+    // sharded batches (heat_batch_set_shared_zones)
+    bool shared_set = false;
+    int n_shared = 0, n_touched = 0;
+    DevBuf<int32_t> d_zlist, d_slot_of, d_shared_zone;
+    std::vector<uint8_t> h_touched;
     DevBuf<double> d_state;
     DevBuf<StepWeather> d_weather;
     DevBuf<int> d_step, d_flags;
@@ -556,6 +561,10 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         }
     }
 
+    // zones this batch's surfaces touch (for sharded batches)
+    b->h_touched.assign(Z, 0);
+    for (int64_t z = 0; z < Z; z++) b->h_touched[z] = zoff[z + 1] > zoff[z] ? 1 : 0;
+
     // ---- host copies used by download ----
     b->h_first_slot.assign(d->first_node_slot, d->first_node_slot + S);
     b->h_node_count.resize(S);
@@ -723,7 +732,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
 void enqueue_zones(heat_batch *b, int mode) {
     launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_side_out.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
-                 b->d_flags.p, mode, b->stream);
+                 b->d_flags.p, mode, b->d_zlist.p, b->n_touched, b->d_slot_of.p, b->n_shared, b->stream);
 }
 
 hipEvent_t next_event(heat_batch *b) {
@@ -933,7 +942,7 @@ int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step) {
     }
     enqueue_surfaces(b, sub_step);
     if (b->timing) HIP_TRY(hipEventRecord(e1, b->stream));
-    enqueue_zones(b, 1);  // partial (a, b) of this rank's surfaces
+    enqueue_zones(b, b->shared_set ? 2 : 1);  // partial (a, b) of this rank's surfaces
     if (b->timing) HIP_TRY(hipEventRecord(e2, b->stream));
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
@@ -947,14 +956,46 @@ int heat_batch_use_partials(heat_batch *b, double *partials_dev) {
     return HEAT_OK;
 }
 
+int heat_batch_touched_zones(const heat_batch *b, uint8_t *mask) {
+    if (!b || (!mask && b->n_zones > 0)) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    for (int64_t z = 0; z < b->n_zones; z++) mask[z] = b->h_touched[z];
+    return HEAT_OK;
+}
+
+int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32_t n_shared) {
+    if (!b || n_shared < 0 || (n_shared > 0 && !shared_zone)) return fail(HEAT_E_INVALID_ARG, "bad argument");
+    int rc = select_device(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    std::vector<int32_t> slot(b->n_zones, -1), zl, sz(shared_zone, shared_zone + n_shared);
+    for (int32_t i = 0; i < n_shared; i++) {
+        if (sz[i] < 0 || sz[i] >= b->n_zones) return fail(HEAT_E_SIZE, "shared zone %d out of range", sz[i]);
+        slot[sz[i]] = i;
+    }
+    for (int64_t z = 0; z < b->n_zones; z++) if (b->h_touched[z]) zl.push_back((int32_t)z);
+    HIP_TRY(b->d_slot_of.upload(slot));
+    HIP_TRY(b->d_zlist.upload(zl));
+    HIP_TRY(b->d_shared_zone.upload(sz));
+    b->n_touched = (int)zl.size();
+    b->n_shared = n_shared;
+    b->shared_set = true;
+    if (b->partial_ptr == b->d_partial.p && (size_t)2 * n_shared > b->d_partial.n)
+        return fail(HEAT_E_SIZE, "partials buffer too small");
+    return HEAT_OK;
+}
+
 int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
     if (n_blocks < 1) return fail(HEAT_E_INVALID_ARG, "n_blocks < 1");
     int rc = select_device(b);
     if (rc) return rc;
     const double *g = gathered_dev ? gathered_dev : b->partial_ptr;
-    launch_zone_update(g, n_blocks, b->d_zone_a0.p, b->d_zone_b0.p, b->d_zone_vol.p, b->d_zone_T.p,
-                       (int)b->n_zones, b->dt, b->d_step.p, b->d_flags.p, b->stream);
+    if (b->shared_set)
+        launch_zone_update_shared(g, n_blocks, b->d_shared_zone.p, b->n_shared, b->d_zone_a0.p, b->d_zone_b0.p,
+                                  b->d_zone_vol.p, b->d_zone_T.p, b->dt, b->d_flags.p, b->stream);
+    else
+        launch_zone_update(g, n_blocks, b->d_zone_a0.p, b->d_zone_b0.p, b->d_zone_vol.p, b->d_zone_T.p,
+                           (int)b->n_zones, b->dt, b->d_step.p, b->d_flags.p, b->stream);
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
 }

@@ -804,16 +804,27 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------
-// Zones: one wavefront per zone. mode 0: full update; mode 1: write partial (a, b) only.
+// Zones: one wavefront per zone.
+//   mode 0: every zone, full update (single GPU).
+//   mode 1: every zone, write the partial (a, b) into partial[2][n_zones] only.
+//   mode 2: sharded: only the zones in zlist[n_list] (those this rank's surfaces touch); a zone no other rank
+//           touches (slot_of[z] < 0) is updated here and now, a shared one writes its partial (a, b) into the
+//           compact partial[2][n_shared] at its slot for the exchange.
 __global__ void __launch_bounds__(256)
 k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entries,
         const double *__restrict__ T, const SideOut *__restrict__ out,
         const double *__restrict__ a0, const double *__restrict__ b0, const double *__restrict__ zone_vol,
         double *__restrict__ zone_T, double *__restrict__ partial, int n_zones, double dt,
-        int *__restrict__ step_ptr, int *__restrict__ flags, int mode) {
+        int *__restrict__ step_ptr, int *__restrict__ flags, int mode, const int32_t *__restrict__ zlist,
+        int n_list, const int32_t *__restrict__ slot_of, int n_shared) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int z = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0 && mode == 0) *step_ptr += 1;
+    int z = wv;
+    if (mode == 2) {
+        if (wv >= n_list) return;
+        z = zlist[wv];
+    }
     if (z >= n_zones) return;
     double a = 0.0, b = 0.0;
     const int64_t e0 = zone_off[z], e1 = zone_off[z + 1];
@@ -834,6 +845,14 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
         partial[z] = a;
         partial[n_zones + z] = b;
         return;
+    }
+    if (mode == 2) {
+        const int slot = slot_of[z];
+        if (slot >= 0) {
+            partial[slot] = a;
+            partial[n_shared + slot] = b;
+            return;
+        }
     }
     a += a0[z];
     b += b0[z];
@@ -858,6 +877,28 @@ k_zone_update(const double *__restrict__ gathered, int n_blocks, const double *_
     for (int r = 0; r < n_blocks; r++) {
         a += gathered[(int64_t)r * 2 * n_zones + z];
         b += gathered[(int64_t)r * 2 * n_zones + n_zones + z];
+    }
+    const double tc = zone_T[z];
+    const double c = zone_mcp(zone_vol[z], tc);
+    double ft = tc;
+    if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);
+    if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);
+    zone_T[z] = ft;
+}
+
+// Shared zones of a sharded batch: gathered = [block][2][n_shared]; zone ids in shared_zone[n_shared].
+__global__ void __launch_bounds__(256)
+k_zone_update_shared(const double *__restrict__ gathered, int n_blocks, const int32_t *__restrict__ shared_zone,
+                     int n_shared, const double *__restrict__ a0, const double *__restrict__ b0,
+                     const double *__restrict__ zone_vol, double *__restrict__ zone_T, double dt,
+                     int *__restrict__ flags) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_shared) return;
+    const int z = shared_zone[s];
+    double a = a0[z], b = b0[z];
+    for (int r = 0; r < n_blocks; r++) {  // rank order: every replica of the zone gets the same bits
+        a += gathered[(int64_t)r * 2 * n_shared + s];
+        b += gathered[(int64_t)r * 2 * n_shared + n_shared + s];
     }
     const double tc = zone_T[z];
     const double c = zone_mcp(zone_vol[z], tc);
@@ -1042,10 +1083,21 @@ void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_ti
 
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
-                  int n_zones, double dt, int *step_ptr, int *flags, int mode, hipStream_t st) {
-    const int nb = n_zones > 0 ? blocks_for_waves(n_zones) : 1;
+                  int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
+                  const int32_t *slot_of, int n_shared, hipStream_t st) {
+    const int n_waves = (mode == 2) ? n_list : n_zones;
+    if (mode == 2 && n_waves <= 0) return;
+    const int nb = n_waves > 0 ? blocks_for_waves(n_waves) : 1;
     hipLaunchKernelGGL(k_zones, dim3(nb), dim3(256), 0, st, zone_off, entries, T, hs, a0, b0, zone_vol, zone_T,
-                       partial, n_zones, dt, step_ptr, flags, mode);
+                       partial, n_zones, dt, step_ptr, flags, mode, zlist, n_list, slot_of, n_shared);
+}
+
+void launch_zone_update_shared(const double *gathered, int n_blocks, const int32_t *shared_zone, int n_shared,
+                               const double *a0, const double *b0, const double *zone_vol, double *zone_T,
+                               double dt, int *flags, hipStream_t st) {
+    if (n_shared <= 0) return;
+    hipLaunchKernelGGL(k_zone_update_shared, dim3((n_shared + 255) / 256), dim3(256), 0, st, gathered, n_blocks,
+                       shared_zone, n_shared, a0, b0, zone_vol, zone_T, dt, flags);
 }
 
 void launch_zone_update(const double *gathered, int n_blocks, const double *a0, const double *b0,

@@ -24,7 +24,11 @@ void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_ti
                            int *flags, unsigned long long *nomass_iters, hipStream_t st);
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
-                  int n_zones, double dt, int *step_ptr, int *flags, int mode, hipStream_t st);
+                  int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
+                  const int32_t *slot_of, int n_shared, hipStream_t st);
+void launch_zone_update_shared(const double *gathered, int n_blocks, const int32_t *shared_zone, int n_shared,
+                               const double *a0, const double *b0, const double *zone_vol, double *zone_T,
+                               double dt, int *flags, hipStream_t st);
 void launch_zone_update(const double *gathered, int n_blocks, const double *a0, const double *b0,
                         const double *zone_vol, double *zone_T, int n_zones, double dt, int *step_ptr,
                         int *flags, hipStream_t st);

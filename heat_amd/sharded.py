@@ -3,11 +3,12 @@
 Surfaces are independent inside a sub-timestep (reference src/model.rs:102-180); the only
 exchange is the zone heat balance ``a[z] = sum h A T_surf``, ``b[z] = sum h A`` over all surfaces
 touching zone z (src/model.rs:556-590). Each rank computes the partial sums of its own surfaces
-(``heat_batch_step_surfaces``), the partial blocks are all-gathered over RCCL/xGMI
-(``torch.distributed`` backend "nccl"; "gloo" on CPU in tests) and every rank applies the zone
-update from the blocks summed in rank order (``heat_batch_step_zones``) — so all replicas of the
-zone temperatures stay bitwise identical and the result does not depend on the collective's
-internal reduction order.
+(``heat_batch_step_surfaces``). Zones that only one rank touches are finished right there; for the
+zones shared between ranks (agreed on once at setup) the partial blocks are all-gathered over
+RCCL/xGMI (``torch.distributed`` backend "nccl"; "gloo" on CPU in tests) and every rank applies the
+zone update from the blocks summed in rank order (``heat_batch_step_zones``) — so all replicas of a
+shared zone's temperature stay bitwise identical and the result does not depend on the collective's
+internal reduction order. A rank does not keep zones it never touches up to date.
 """
 import numpy as np
 
@@ -26,24 +27,47 @@ def shard_model(md, rank, n_ranks):
     return mdl.subset(md, np.arange(b[rank], b[rank + 1]))
 
 
-class ZoneExchange:
-    """All-gather of the per-rank partial (a, b) blocks: [2 * n_zones] -> [n_ranks, 2 * n_zones]."""
+def shared_zones(touched_masks):
+    """touched_masks: [n_ranks, n_zones] 0/1. Returns the sorted global numbers of the zones that more than one
+    rank touches (the only zones whose heat balance needs an exchange)."""
+    m = np.asarray(touched_masks)
+    return np.nonzero(m.astype(np.int64).sum(axis=0) >= 2)[0].astype(np.int32)
 
-    def __init__(self, n_zones, device, group=None):
+
+class ZoneExchange:
+    """All-gather of the per-rank partial (a, b) blocks of the SHARED zones:
+    [2 * n_shared] per rank -> [n_ranks, 2 * n_shared] on every rank (block order = rank order)."""
+
+    def __init__(self, n_shared, device, group=None):
         import torch
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.partial = torch.zeros(2 * n_zones, dtype=torch.float64, device=device)
-        self.gathered = torch.zeros(self.world * 2 * n_zones, dtype=torch.float64, device=device)
+        self.n_shared = int(n_shared)
+        n = max(2 * self.n_shared, 2)
+        self.partial = torch.zeros(n, dtype=torch.float64, device=device)
+        self.gathered = torch.zeros(self.world * n, dtype=torch.float64, device=device)
 
     def all_gather(self):
+        if self.n_shared == 0:
+            return self.gathered
         if self.world == 1:
             self.gathered.copy_(self.partial)
         else:
             self.dist.all_gather_into_tensor(self.gathered, self.partial, group=self.group)
         return self.gathered
+
+
+def agree_on_shared_zones(local_mask, device, group=None):
+    """Every rank contributes its touched-zone mask; all get the same shared-zone list."""
+    import torch
+    import torch.distributed as dist
+    m = torch.as_tensor(np.asarray(local_mask, dtype=np.int32), device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+        return np.nonzero(m.cpu().numpy() >= 2)[0].astype(np.int32)
+    return np.zeros(0, dtype=np.int32)
 
 
 class ShardedMarch:
@@ -66,7 +90,10 @@ class ShardedMarch:
         self.stream = torch.cuda.Stream(device=device_index)
         self.batch = HeatBatch(md_shard, device=device_index, stream=self.stream.cuda_stream, n_ranks=n_ranks,
                                rank=rank, **batch_opts)
-        self.exchange = ZoneExchange(int(md_shard["n_zones"]), torch.device("cuda", device_index))
+        dev = torch.device("cuda", device_index)
+        self.shared = agree_on_shared_zones(self.batch.touched_zones(), dev)
+        self.batch.set_shared_zones(self.shared)
+        self.exchange = ZoneExchange(len(self.shared), dev)
         self.batch.use_partials(self.exchange.partial.data_ptr())
         self.n_ranks = n_ranks
 
@@ -76,9 +103,10 @@ class ShardedMarch:
         with self.torch.cuda.stream(self.stream):
             b.set_weather(weather, zone_a0, zone_b0)
             for i in range(len(weather)):
-                b.step_surfaces(i)
-                g = self.exchange.all_gather()
-                b.step_zones(g.data_ptr(), self.exchange.world)
+                b.step_surfaces(i)      # local kernels; zones only this rank touches are updated in place
+                if len(self.shared):
+                    g = self.exchange.all_gather()
+                    b.step_zones(g.data_ptr(), self.exchange.world)
 
     def synchronize(self):
         self.batch.synchronize()

@@ -187,6 +187,15 @@ double *heat_batch_zone_partials(heat_batch *b); /* device pointer, [2][n_zones]
 /* Makes step_surfaces write the partial sums into caller-owned device memory ([2][n_zones] doubles,
  * e.g. a tensor the caller hands to its collective); NULL restores the batch's own buffer. */
 int heat_batch_use_partials(heat_batch *b, double *partials_dev);
+/* Sharded batches, compact exchange. heat_batch_touched_zones fills mask[n_zones] with 1 for every zone a surface
+ * of this batch faces. After the ranks have agreed on the zones more than one of them touches,
+ * heat_batch_set_shared_zones(shared_zone[n_shared]: global zone numbers, the same list in the same order on every
+ * rank) switches the split-phase sequence to the compact form: heat_batch_step_surfaces updates the zones only this
+ * rank touches at once and writes the partial (a, b) of the shared ones into the partials buffer, laid out
+ * [2][n_shared]; heat_batch_step_zones(gathered, n_blocks) then updates the shared zones from the gathered blocks
+ * [block][2][n_shared], summed in block order. Zones this rank does not touch are not kept up to date on it. */
+int heat_batch_touched_zones(const heat_batch *b, uint8_t *mask);
+int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32_t n_shared);
 
 /* Introspection (tests, bench). */
 int64_t heat_batch_n_surfaces(const heat_batch *b);

@@ -40,7 +40,56 @@ def main():
     for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
                 md["flow_back_slot"], md["zone_slot"]):
         assert np.allclose(got[idx], ref[idx], rtol=1e-9, atol=1e-9)
+    two_shards_on_one_gpu()
     print("SHARDED OK")
+
+
+def two_shards_on_one_gpu():
+    """The compact zone exchange with two real shards: two batches on one GPU play rank 0 and rank 1, the
+    'all-gather' is a concatenation of their partial buffers. Exercises k_zones mode 2 and k_zone_update_shared
+    with n_blocks = 2 on the device."""
+    from heat_amd import HeatBatch
+    from heat_amd.sharded import shard_model, shared_zones
+    md, st = mdl.ragged_mixed(900, Z=9, dt=45.0, seed=33)
+    w = mdl.weather_series(7, 45.0)
+    a0 = np.linspace(0., 50., 9)
+    b0 = np.linspace(0., 3., 9)
+    ref = st.copy()
+    rc, _ = orc.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    stream = torch.cuda.Stream()
+    shards = [shard_model(md, r, 2) for r in range(2)]
+    batches = [HeatBatch(sh, stream=stream.cuda_stream, n_ranks=2, rank=r) for r, sh in enumerate(shards)]
+    masks = [b.touched_zones() for b in batches]
+    shared = shared_zones(masks)
+    assert 0 < len(shared) < 9
+    ns = len(shared)
+    parts = [torch.zeros(2 * ns, dtype=torch.float64, device="cuda") for _ in range(2)]
+    states = [st.copy(), st.copy()]
+    with torch.cuda.stream(stream):
+        for b, p, s_ in zip(batches, parts, states):
+            b.set_shared_zones(shared)
+            b.use_partials(p.data_ptr())
+            b.upload_state(s_)
+            b.set_weather(w, a0, b0)
+        for i in range(len(w)):
+            for b in batches:
+                b.step_surfaces(i)
+            g = torch.cat(parts)
+            for b in batches:
+                b.step_zones(g.data_ptr(), 2)
+        for b, s_ in zip(batches, states):
+            b.synchronize()
+            b.download_state(s_)
+    for r in range(2):
+        sh = shards[r]
+        for idx in (mdl.node_slots(sh), sh["hs_front_slot"], sh["hs_back_slot"], sh["flow_front_slot"], sh["flow_back_slot"]):
+            assert np.allclose(states[r][idx], ref[idx], rtol=1e-9, atol=1e-9)
+        mine = np.nonzero(masks[r])[0]
+        assert np.allclose(states[r][md["zone_slot"][mine]], ref[md["zone_slot"][mine]], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(states[0][md["zone_slot"][shared]], states[1][md["zone_slot"][shared]])
+    for b in batches:
+        b.close()
 
 
 if __name__ == "__main__":

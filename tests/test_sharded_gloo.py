@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     from heat_amd import modeldict as mdl
-    from heat_amd.sharded import ZoneExchange, shard_model, shard_ranges
+    from heat_amd.sharded import ZoneExchange, agree_on_shared_zones, shard_model, shard_ranges
     from oracle import oracle as orc
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -51,30 +51,46 @@ def _worker(rank, world, port, q):
         bounds = shard_ranges(md["n_surfaces"], world)
         assert shard["n_surfaces"] == bounds[rank + 1] - bounds[rank]
         om = orc.OracleModel(shard)
-        ex = ZoneExchange(Z, torch.device("cpu"))
+        # zones this rank touches (what heat_batch_touched_zones reports) -> shared list, agreed over gloo
+        touched = np.zeros(Z, dtype=np.uint8)
+        touched[shard["front_zone"][shard["front_kind"] == mdl.SPACE]] = 1
+        touched[shard["back_zone"][shard["back_kind"] == mdl.SPACE]] = 1
+        shared = agree_on_shared_zones(touched, torch.device("cpu"))
+        assert len(shared) > 0 and len(shared) < Z          # some zones span both ranks, some do not
+        ns = len(shared)
+        ex = ZoneExchange(ns, torch.device("cpu"))
         assert ex.world == world
         state = state0.copy()
+        mine = np.nonzero(touched)[0]
+        local_only = np.setdiff1d(mine, shared)
         for i in range(len(weather)):
             t_cur = state[md["zone_slot"]].copy()
             rc, _ = om.iterate_surfaces(state, weather[i, 1], weather[i, 2], weather[i, 0])
             assert rc == 0
             a, b, c = om.zones_abc(state)          # this rank's partial sums (+ c from the zone state)
-            ex.partial[:Z] = torch.from_numpy(a)
-            ex.partial[Z:] = torch.from_numpy(b)
-            g = ex.all_gather().numpy().reshape(world, 2, Z)
-            at, bt = a0.copy(), b0.copy()
-            for r in range(world):                  # rank-ordered sum, as k_zone_update does
+            ft = t_cur.copy()
+            # zones only this rank touches: finished locally (k_zones mode 2)
+            at, bt = a0 + a, b0 + b
+            upd = np.where(np.abs(bt) > 1e-9, at / bt + (t_cur - at / bt) * np.exp(-bt * md["dt"] / c), t_cur)
+            ft[local_only] = upd[local_only]
+            # shared zones: compact exchange, rank-ordered sum (k_zone_update_shared)
+            ex.partial[:ns] = torch.from_numpy(a[shared])
+            ex.partial[ns:2 * ns] = torch.from_numpy(b[shared])
+            g = ex.all_gather().numpy().reshape(world, -1)[:, :2 * ns].reshape(world, 2, ns)
+            at, bt = a0[shared].copy(), b0[shared].copy()
+            for r in range(world):
                 at += g[r, 0]
                 bt += g[r, 1]
-            ft = np.where(np.abs(bt) > 1e-9, at / bt + (t_cur - at / bt) * np.exp(-bt * md["dt"] / c), t_cur)
+            cs, ts = c[shared], t_cur[shared]
+            ft[shared] = np.where(np.abs(bt) > 1e-9, at / bt + (ts - at / bt) * np.exp(-bt * md["dt"] / cs), ts)
             state[md["zone_slot"]] = ft
-        # every rank holds identical zone temperatures, equal to the single-process result
-        zt = torch.from_numpy(state[md["zone_slot"]].copy())
-        both = torch.zeros(world * Z, dtype=torch.float64)
+        # the zones this rank touches equal the single-process result; shared zones are identical on both ranks
+        assert np.allclose(state[md["zone_slot"]][mine], ref[md["zone_slot"]][mine], rtol=1e-9, atol=1e-9)
+        zt = torch.from_numpy(state[md["zone_slot"]][shared].copy())
+        both = torch.zeros(world * ns, dtype=torch.float64)
         dist.all_gather_into_tensor(both, zt)
-        both = both.numpy().reshape(world, Z)
+        both = both.numpy().reshape(world, ns)
         assert np.array_equal(both[0], both[1])
-        assert np.allclose(both[0], ref[md["zone_slot"]], rtol=1e-9, atol=1e-9)
         # this rank's surfaces match the single-process march
         ns = mdl.node_slots(shard)
         assert np.allclose(state[ns], ref[ns], rtol=1e-9, atol=1e-9)
