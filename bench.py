@@ -118,6 +118,12 @@ def main():
                     help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: anything a library prints meanwhile (RCCL's version
+    # banner under NCCL_DEBUG=VERSION goes to stdout) is sent to stderr instead.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,6 +235,9 @@ def main():
         dist.destroy_process_group()
     else:
         batch.close()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(result), flush=True)
 
