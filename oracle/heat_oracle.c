@@ -19,7 +19,7 @@
 
 #define OR_PI 3.14159265358979323846264338327950288 /* lib.rs:45 (std::f64::consts::PI) */
 #define OR_SIGMA 5.670374419e-8                     /* lib.rs:49 */
-#define OR_MAX_NODES 512
+#define OR_MAX_NODES 1024
 
 /* f64::powi as lowered through compiler-rt's __powidf2. */
 static double or_powi(double a, int b) {

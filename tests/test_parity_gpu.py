@@ -46,7 +46,7 @@ def assert_state_close(md, ref, got):
     for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
                 md["flow_back_slot"], md["zone_slot"]):
         owned[idx] = True
-    assert np.array_equal(ref[~owned], got[~owned])
+    assert np.array_equal(ref[~owned], got[~owned], equal_nan=True)
 
 
 @pytest.mark.parametrize("npl,no_palette", [(0, False), (4, False), (8, False), (16, False), (0, True), (4, True),
@@ -322,5 +322,58 @@ def test_cavities_on_the_fast_path_and_their_fallbacks(oracle):
     for npl in (0, 4, 8, 16):
         ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, nodes_per_lane=npl)
         assert sum(counts[:3]) > 0 and counts[4] > 0, counts
+        assert iters == gpu_iters
+        assert_state_close(md, ref, got)
+
+
+def test_edge_cases_empty_tiny_and_long_walls(oracle):
+    """Empty batch, zones without surfaces, one-node and very long walls (catch-all kernel), NaN / negative solar
+    input (clamps of surface.rs:916-923), zero wind, all through the C ABI."""
+    # empty batch with zones: marching only applies the zone formula with a0/b0
+    md = mdl.empty(0, 2, 45.0)
+    md["node_offset"] = np.zeros(1, dtype=np.int64)
+    for k in ("mass", "uvalue", "front_alpha", "back_alpha", "front_ambient", "back_ambient", "front_emissivity",
+              "back_emissivity", "area", "perimeter", "cos_tilt", "normal_x", "normal_y", "wind_modifier"):
+        md[k] = np.zeros(0)
+    for k in ("front_kind", "back_kind", "front_zone", "back_zone"):
+        md[k] = np.zeros(0, dtype=np.int32)
+    md["zone_volume"] = np.array([50., 80.])
+    st = mdl.layout_state(md)
+    w = mdl.weather_series(5, 45.0)
+    a0, b0 = np.array([300., 0.]), np.array([10., 0.])
+    ref, got, *_ = run_both(oracle, md, st, w, a0, b0)
+    assert np.allclose(got, ref, rtol=RTOL, atol=ATOL) and got[1] == 22.0 and got[0] != 22.0
+
+    # long walls (n = 200 > 64 lanes * ... still fast path) and n = 1000 (k > 64 at M = 4 -> catch-all when forced)
+    for n, npl in ((200, 4), (1000, 4), (1000, 16)):
+        md, st = mdl.uniform_massive(9, n, Z=2, dt=20.0, seed=n)
+        ref, got, _, _, counts = run_both(oracle, md, st, mdl.weather_series(6, 20.0), nodes_per_lane=npl)
+        assert_state_close(md, ref, got)
+        if n == 1000 and npl == 4:
+            assert counts[4] == 9  # 250 lanes per surface do not fit a wavefront
+
+    # weird inputs
+    md, st = mdl.ragged_mixed(300, Z=3, dt=45.0, seed=4)
+    st[md["solar_front_slot"][::3]] = np.nan
+    st[md["solar_front_slot"][1::3]] = -50.0
+    st[md["solar_back_slot"][::2]] = np.nan
+    st[md["solar_back_slot"][1::2]] = -20.0   # passes through unclamped (the reference's quirk)
+    w = mdl.weather_series(8, 45.0, wind_speed=0.0)
+    ref, got, iters, gpu_iters, _ = run_both(oracle, md, st, w)
+    assert iters == gpu_iters
+    assert_state_close(md, ref, got)
+
+
+def test_one_node_surfaces(oracle):
+    """A single-node wall (n = 1: both faces on the same node), massive and no-mass."""
+    for mass in (5.0e4, 0.0):
+        segs = dict(mass=np.array([mass]), uvalue=np.array([0.0]), front_alpha=np.array([0.3]),
+                    back_alpha=np.array([0.2]))
+        md, st = surfaces_model(segs, 30.0, mdl.OUTDOOR, mdl.SPACE, n_zones=1, zone_volume=[30.], front_emis=0.1,
+                                back_emis=0.1, cos_tilt=0.0, normal=(0., -1., 0.), copies=70)
+        st[md["solar_front_slot"]] = 200.0
+        st[md["ir_front_slot"]] = mdl.SIGMA * 283.15 ** 4
+        st[mdl.node_slots(md)] = np.linspace(15., 30., 70)
+        ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, mdl.weather_series(10, 30.0))
         assert iters == gpu_iters
         assert_state_close(md, ref, got)
