@@ -128,3 +128,70 @@ def test_tarp_coefficients_track_energyplus(oracle, case, normal):
     print("%s: hs_in RMSE %.4f (mean %.3f), hs_out RMSE %.4f (mean %.3f)" % (
         case, rm_in, fx["hs_in"].mean(), rm_out, fx["hs_out"].mean()))
     assert rm_in < 0.1 and rm_out < 0.1
+
+
+# ---------------------------------------------------------------------------------------------------
+# The reference's closed-form cases (validate_wall_heat_transfer.rs:30-93, 181-613): a no-mass polyurethane
+# wall 2 m x 2 m, zone of 40 m3, convection coefficients forced to 10 W/m2K, constant 30 C outside; optional
+# heater / luminaire power and infiltration, which reach the path as the host-side zone terms a0, b0.
+def closed_form_case(oracle, n_per_hour, steps, heating_power=0.0, lighting_power=0.0, infiltration_rate=0.0,
+                     march=None):
+    L = oracle.lib()
+    zone_volume, area, t_out, t_start = 40., 4., 30.0, 22.0
+    poly = dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400., front_thermal_abs=0., back_thermal_abs=0.)
+    main_dt = 3600. / n_per_hour
+    d = oracle.discretize([poly], main_dt, 0.04, 60., 1., math.pi / 2)
+    assert d["n_nodes"] == 2 and d["n_elements"] == [0]                      # no-mass wall
+    sub = d["tstep_subdivision"]
+    dt, n_sub = 3600. / (n_per_hour * sub) / 2., 2 * sub
+    md, state = surfaces_model(d, dt, mdl.OUTDOOR, mdl.SPACE, n_zones=1, zone_volume=[zone_volume], area=area,
+                               perimeter=8., cos_tilt=0.0, normal=(0., -1., 0.), height=1.0, hs_fix=(10., 10.))
+    # host-side zone terms, model.rs:500-544
+    a0 = np.array([heating_power + lighting_power])
+    b0 = np.array([0.0])
+    if infiltration_rate > 0.0:
+        cp_inf = L.or_gas_heat_capacity(oracle.AIR, t_out + 273.15)
+        rho_inf = L.or_gas_density(oracle.AIR, t_out + 273.15)
+        a0[0] += rho_inf * infiltration_rate * cp_inf * t_out
+        b0[0] += rho_inf * infiltration_rate * cp_inf
+    # closed solution, validate_wall_heat_transfer.rs:62-93
+    rho = L.or_gas_density(oracle.AIR, 22. + 273.15)
+    cp = L.or_gas_heat_capacity(oracle.AIR, 22. + 273.15)
+    r = 1. / d["uvalue"][0] + 1. / 10. + 1. / 10.      # discretization.r_value() + 1/hs_front + 1/hs_back
+    u = 1. / r
+    c = zone_volume * rho * cp
+    a = heating_power + lighting_power + t_out * u * area + infiltration_rate * rho * cp * t_out
+    b = u * area + rho * infiltration_rate * cp
+    exp_fn = lambda t: a / b + (t_start - a / b) * math.exp(-b * t / c)
+    m = oracle.OracleModel(md)
+    w = np.tile([t_out, 0.0, 0.0], (n_sub, 1))
+    found, exp = np.zeros(steps), np.zeros(steps)
+    for i in range(steps):
+        found[i] = state[md["zone_slot"][0]]
+        exp[i] = exp_fn(i * main_dt)
+        if march is None:
+            rc, _ = m.march(state, w, a0, b0)
+            assert rc == 0
+        else:
+            march(state, w, a0, b0)
+    return md, state, found, exp
+
+
+CLOSED_FORM = {
+    # name: (n per hour, steps, kwargs) — the registered cases of validate_wall_heat_transfer.rs:752-790 that
+    # do not need the (unseen) window geometry of simple_test_models
+    "nomass_wallonly": (60, 1000, {}),
+    "luminaire_on": (20, 800, dict(lighting_power=100.)),
+    "heater_on": (20, 800, dict(heating_power=100.)),
+    "heater_and_infiltration": (20, 800, dict(heating_power=10., infiltration_rate=0.1)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CLOSED_FORM))
+def test_closed_form_zone_solutions(oracle, case):
+    n, steps, kw = CLOSED_FORM[case]
+    md, state, found, exp = closed_form_case(oracle, n, steps, **kw)
+    err = np.abs(found - exp)
+    print("%s: max |found - closed form| = %.4f C, final %.3f vs %.3f" % (case, err.max(), found[-1], exp[-1]))
+    assert err.max() < 0.35
+    assert abs(found[-1] - exp[-1]) < 0.05

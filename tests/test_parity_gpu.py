@@ -377,3 +377,26 @@ def test_one_node_surfaces(oracle):
         ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, mdl.weather_series(10, 30.0))
         assert iters == gpu_iters
         assert_state_close(md, ref, got)
+
+
+@pytest.mark.parametrize("case", ["nomass_wallonly", "heater_on", "heater_and_infiltration"])
+def test_closed_form_cases_through_the_abi(oracle, case):
+    """The reference's closed-form validation cases (validate_wall_heat_transfer.rs:181-613) with the host-side
+    zone terms a0 / b0 (heater, infiltration) handed to heat_batch_march, against the oracle and the closed form."""
+    from test_energyplus_series import CLOSED_FORM, closed_form_case
+    n, steps, kw = CLOSED_FORM[case]
+    steps = min(steps, 300)
+    md, ref_state, ref, exp = closed_form_case(oracle, n, steps, **kw)
+    holder = {}
+
+    def gpu_march(state, w, a0, b0):
+        if "b" not in holder:
+            holder["b"] = HeatBatch(md)
+            holder["b"].upload_state(state)
+        holder["b"].march(state, w, a0, b0)
+
+    md2, got_state, got, _ = closed_form_case(oracle, n, steps, march=gpu_march, **kw)
+    holder["b"].close()
+    assert np.allclose(got, ref, rtol=RTOL, atol=ATOL)
+    assert_state_close(md, ref_state, got_state)
+    assert np.abs(got - exp).max() < 0.35
