@@ -41,5 +41,21 @@ def build(force=False, verbose=False):
     return LIB
 
 
+EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "march_walls.cpp")
+EXAMPLE_BIN = os.path.join(LIB_DIR, "march_walls")
+
+
+def build_example(force=False):
+    """examples/march_walls.cpp: a compiled (C++) host that drives the path through the C ABI only."""
+    build()
+    if not force and os.path.exists(EXAMPLE_BIN) and os.path.getmtime(EXAMPLE_BIN) >= max(
+            os.path.getmtime(EXAMPLE_SRC), os.path.getmtime(LIB)):
+        return EXAMPLE_BIN
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(HERE, "..", "include"), EXAMPLE_SRC,
+                           "-L", LIB_DIR, "-lheat_amd", "-Wl,-rpath,$ORIGIN", "-o", EXAMPLE_BIN])
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_example(force="--force" in sys.argv))

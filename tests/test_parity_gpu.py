@@ -400,3 +400,48 @@ def test_closed_form_cases_through_the_abi(oracle, case):
     assert np.allclose(got, ref, rtol=RTOL, atol=ATOL)
     assert_state_close(md, ref_state, got_state)
     assert np.abs(got - exp).max() < 0.35
+
+
+def test_compiled_cpp_host_on_the_c_abi(oracle):
+    """examples/march_walls.cpp (no Python in the loop: model builder -> heat_batch_create -> heat_batch_march on a
+    caller-owned state) prints what the oracle computes for the same building."""
+    import subprocess
+    from heat_amd import ModelBuilder, build as hb
+    exe = hb.build_example()
+    n_walls, n_steps = 12, 10
+    out = subprocess.run([exe, str(n_walls), str(n_steps)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    # the same building, built here
+    ins = dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400., front_thermal_abs=0.2, back_thermal_abs=0.2,
+               front_solar_abs=0.7, back_solar_abs=0.7)
+    conc = dict(thickness=0.2, k=0.816, rho=1700., cp=800., front_thermal_abs=0.9, back_thermal_abs=0.9,
+                front_solar_abs=0.7, back_solar_abs=0.7)
+    mb = ModelBuilder(20)
+    za, zb = mb.add_zone(600.0), mb.add_zone(250.0)
+    for i in range(n_walls):
+        layers = [conc] if i % 3 == 0 else ([ins, conc, ins] if i % 3 == 1 else [ins])
+        area = 10.0 + i
+        az = 0.4 * i
+        mb.add_surface(layers, area, 2.0 * (area / 3.0 + 3.0), (math.sin(az), math.cos(az), 0.0), 1.5 + 3.0 * (i % 4),
+                       mdl.SPACE if i % 5 == 4 else mdl.OUTDOOR, mdl.SPACE, front_zone=zb, back_zone=zb if i % 2 else za)
+    md, state, n_sub = mb.finish()
+    m = oracle.OracleModel(md)
+    for step in range(n_steps):
+        s_ = np.arange(n_walls)
+        state[md["solar_front_slot"]] = 50.0 * (step % 7) + 3.0 * s_
+        state[md["ir_front_slot"]] = 5.670374419e-8 * (283.15 + step) ** 4
+        state[md["ir_back_slot"]] = 5.670374419e-8 * 295.15 ** 4
+        w = np.tile([10.0 + 0.5 * step, (150.0 + 10.0 * step) * (math.pi / 180.0), 2.0 + 0.1 * step], (n_sub, 1))
+        rc, _ = m.march(state, w, np.array([150.0, 0.0]), np.array([0.0, 0.0]))
+        assert rc == 0
+    head = lines[0].split()
+    assert int(head[1]) == md["n_state"] and float(head[3]) == md["dt"] and int(head[5]) == n_sub
+    zones = [float(l.split()[2]) for l in lines if l.startswith("zone")]
+    assert np.allclose(zones, state[md["zone_slot"]], rtol=RTOL, atol=ATOL)
+    surf = np.array([[float(x) for x in l.split()[2:]] for l in lines if l.startswith("surface")])
+    n = np.diff(md["node_offset"])
+    exp = np.stack([state[md["first_node_slot"]], state[md["first_node_slot"] + n - 1], state[md["hs_front_slot"]],
+                    state[md["flow_back_slot"]]], axis=1)
+    assert np.allclose(surf, exp, rtol=RTOL, atol=ATOL)
+    mb.close()
