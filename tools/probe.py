@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from heat_amd import HeatBatch, modeldict as mdl
 from oracle import oracle as orc
 

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from heat_amd import HeatBatch, modeldict as mdl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from heat_amd import HeatBatch, modeldict as mdl
 S = 1000000
