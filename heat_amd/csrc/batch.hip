@@ -222,9 +222,9 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
     int M = opt.nodes_per_lane;
     if (M == 0) {
         // Nodes are padded to a multiple of M inside the last lane. Measured cost per padded node
-        // (1 M x 32 nodes, profiles/README.md): M = 16 : 8 : 4 = 1.00 : 1.05 : 1.16 — larger blocks amortise
-        // the per-surface boundary work over more nodes. Pick the cheapest.
-        const double w[3] = {1.16, 1.05, 1.00};
+        // (1 M x 32 and 1 M x 20 nodes, profiles/README.md): M = 16 : 8 : 4 = 1.00 : 1.03 : 1.30 — larger blocks
+        // amortise the per-surface boundary work over more nodes. Pick the cheapest.
+        const double w[3] = {1.30, 1.03, 1.00};
         const int ms[3] = {4, 8, 16};
         double best = 0.0;
         for (int q = 0; q < 3; q++) {

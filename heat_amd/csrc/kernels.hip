@@ -1040,7 +1040,8 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     // A class that has the chip to itself runs persistently; classes that run side by side on several streams
     // launch one wave per tile and let the dispatcher interleave them (measured: dividing the chip between
     // persistent grids by work share was 1.7x slower on the ragged config).
-    const bool persistent = tune > 0 && grid_share > 0.999;
+    // (M = 4 tiles are too small for it: 1 M x 20 nodes ran 172 us persistent vs 155 us one wave per tile.)
+    const bool persistent = tune > 0 && grid_share > 0.999 && M >= 8;
     const dim3 grid(persistent ? std::min(full_grid, n_cu * blocks_per_cu) : full_grid), block(256);
 #define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                       \
     hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
