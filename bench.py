@@ -116,6 +116,11 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
+    ap.add_argument("--force-shared-zones", type=int, default=0,
+                    help="single-GPU rehearsal of the exchange: declare this many zones shared (implies --force-sharded)")
+    ap.add_argument("--collective", choices=("native", "torch"), default="native",
+                    help="sharded: library-owned RCCL communicator, all in one stream (default), or "
+                         "torch.distributed.all_gather_into_tensor between the split-phase calls")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON result: anything a library prints meanwhile (RCCL's version
@@ -139,7 +144,7 @@ def main():
     weather_w = mdl.weather_series(max(W, 1), dt)
     weather_k = mdl.weather_series(K, dt, t0=dt * W)
 
-    sharded = world > 1 or args.force_sharded
+    sharded = world > 1 or args.force_sharded or args.force_shared_zones > 0
     if sharded:
         import torch
         import torch.distributed as dist
@@ -149,8 +154,11 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        sm = ShardedMarch(md, rank, world, device_index=local_rank, nodes_per_lane=args.nodes_per_lane,
-                          no_palette=args.no_palette)
+        forced = None
+        if args.force_shared_zones > 0:
+            forced = np.unique(np.linspace(0, args.zones_per_gpu * world - 1, args.force_shared_zones).astype(np.int32))
+        sm = ShardedMarch(md, rank, world, device_index=local_rank, collective=args.collective, force_shared=forced,
+                          nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette)
         batch = sm.batch
         batch.upload_state(state)
 
@@ -213,7 +221,10 @@ def main():
             "surfaces_per_gpu": args.surfaces, "nodes_per_surface": args.nodes,
             "zones_per_gpu": args.zones_per_gpu, "dt_s": dt,
             "kernel_classes[M4,M8,M16,small,general]": counts,
-            "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep all-gather of zone partials" % world
+            "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep RCCL all-gather of the partial "
+                           "sums of %d shared zones (%s)" % (
+                               world, sm.n_shared_zones,
+                               "library-owned communicator, one stream" if args.collective == "native" else "torch.distributed")
             if sharded else "single GPU",
         },
     }

@@ -99,6 +99,9 @@ SYMBOLS = [
     ("heat_batch_use_partials", C.c_int, [_H, C.c_void_p]),
     ("heat_batch_touched_zones", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("heat_batch_set_shared_zones", C.c_int, [_H, _i32p, C.c_int32]),
+    ("heat_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("heat_batch_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
+    ("heat_batch_n_shared_zones", C.c_int32, [_H]),
     ("heat_batch_n_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_nodes", C.c_int64, [_H]),
     ("heat_batch_n_zones", C.c_int64, [_H]),
@@ -217,6 +220,13 @@ def make_desc(md):
     return d, keep
 
 
+def comm_unique_id():
+    """ncclGetUniqueId through the library (128 bytes). One rank calls it and hands the bytes to the others."""
+    buf = (C.c_uint8 * 128)()
+    _check(load_library().heat_comm_unique_id(buf))
+    return bytes(buf)
+
+
 class HeatBatch:
     """Device-resident batch of surfaces + zones (≙ ThermalModel, src/model.rs:54-77)."""
 
@@ -319,6 +329,16 @@ class HeatBatch:
     def set_shared_zones(self, shared_zone):
         sz = np.ascontiguousarray(shared_zone, dtype=np.int32)
         _check(self._L.heat_batch_set_shared_zones(self._h, sz.ctypes.data_as(_i32p), len(sz)))
+
+    def comm_init(self, unique_id):
+        """ncclCommInitRank with the 128-byte id of comm_unique_id() (collective: every rank calls it), then the
+        ranks agree on the shared zones. After it the batch marches like a single-GPU one."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(self._L.heat_batch_comm_init(self._h, buf))
+
+    @property
+    def n_shared_zones(self):
+        return int(self._L.heat_batch_n_shared_zones(self._h))
 
     def set_timing(self, enabled):
         _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))

@@ -5,6 +5,9 @@
 // There is no CPU fallback: every entry point that computes needs a HIP device and fails
 // with HEAT_E_DEVICE otherwise.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is loaded at run time (heat_batch_comm_init), never linked
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -40,6 +43,51 @@ int fail(int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess)                                                                      \
             return fail(HEAT_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// RCCL entry points, bound at run time so that single-GPU users need no RCCL at all. In a process that
+// has loaded torch, "librccl.so.1" resolves to the copy torch already mapped (same soname).
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return nullptr;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString) {
+        dlclose(h);
+        return nullptr;
+    }
+    r.handle = h;
+    return &r;
+}
+
+#define RCCL_TRY(R, expr)                                                                             \
+    do {                                                                                              \
+        ncclResult_t e_ = (expr);                                                                     \
+        if (e_ != ncclSuccess)                                                                        \
+            return fail(HEAT_E_COMM, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
 template <typename T>
@@ -136,6 +184,9 @@ struct heat_batch {
     int n_shared = 0, n_touched = 0;
     DevBuf<int32_t> d_zlist, d_slot_of, d_shared_zone;
     std::vector<uint8_t> h_touched;
+    // library-owned collective (heat_batch_comm_init): RCCL communicator + the gathered partial blocks
+    ncclComm_t comm = nullptr;
+    DevBuf<double> d_gathered;  // [n_ranks][2][n_shared]
     DevBuf<double> d_state;
     DevBuf<StepWeather> d_weather;
     DevBuf<int> d_step, d_flags;
@@ -164,6 +215,10 @@ struct heat_batch {
     size_t ev_used = 0;
 
     ~heat_batch() {
+        if (comm) {
+            Rccl *r = rccl();
+            if (r) (void)r->CommDestroy(comm);
+        }
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
         for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -963,7 +1018,9 @@ int heat_batch_touched_zones(const heat_batch *b, uint8_t *mask) {
 }
 
 int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32_t n_shared) {
-    if (!b || n_shared < 0 || (n_shared > 0 && !shared_zone)) return fail(HEAT_E_INVALID_ARG, "bad argument");
+    static const int32_t none = 0;
+    if (n_shared == 0 && !shared_zone) shared_zone = &none;
+    if (!b || n_shared < 0 || !shared_zone) return fail(HEAT_E_INVALID_ARG, "bad argument");
     int rc = select_device(b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -979,10 +1036,48 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
     b->n_touched = (int)zl.size();
     b->n_shared = n_shared;
     b->shared_set = true;
+    if (b->comm) HIP_TRY(b->d_gathered.zeros((size_t)b->n_ranks * 2 * std::max(n_shared, 1)));
     if (b->partial_ptr == b->d_partial.p && (size_t)2 * n_shared > b->d_partial.n)
         return fail(HEAT_E_SIZE, "partials buffer too small");
     return HEAT_OK;
 }
+
+int heat_comm_unique_id(uint8_t id[HEAT_COMM_ID_BYTES]) {
+    if (!id) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    Rccl *r = rccl();
+    if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", dlerror() ? dlerror() : "symbols missing");
+    static_assert(sizeof(ncclUniqueId) == HEAT_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    RCCL_TRY(r, r->GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return HEAT_OK;
+}
+
+int heat_batch_comm_init(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES]) {
+    if (!b || !id) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    if (b->comm) return fail(HEAT_E_INVALID_ARG, "the batch already has a communicator");
+    Rccl *r = rccl();
+    if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", dlerror() ? dlerror() : "symbols missing");
+    int rc = select_device(b);
+    if (rc) return rc;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RCCL_TRY(r, r->CommInitRank(&b->comm, b->n_ranks, u, b->rank));
+    // agree on the zones more than one rank touches: sum of the touched masks
+    const int64_t Z = b->n_zones;
+    std::vector<int32_t> mask(std::max<int64_t>(Z, 1), 0);
+    for (int64_t z = 0; z < Z; z++) mask[z] = b->h_touched[z];
+    DevBuf<int32_t> d_mask;
+    HIP_TRY(d_mask.upload(mask));
+    RCCL_TRY(r, r->AllReduce(d_mask.p, d_mask.p, mask.size(), ncclInt32, ncclSum, b->comm, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(mask.data(), d_mask.p, mask.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> shared;
+    for (int64_t z = 0; z < Z; z++) if (mask[z] >= 2) shared.push_back((int32_t)z);
+    return heat_batch_set_shared_zones(b, shared.data(), (int32_t)shared.size());
+}
+
+int32_t heat_batch_n_shared_zones(const heat_batch *b) { return (b && b->shared_set) ? b->n_shared : 0; }
 
 int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
@@ -1003,10 +1098,42 @@ int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_b
 int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_t n_sub, const double *zone_a0,
                               const double *zone_b0) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
-    if (b->n_ranks > 1)
-        return fail(HEAT_E_INVALID_ARG, "sharded batch: drive it with heat_batch_step_surfaces / heat_batch_step_zones");
+    if (b->n_ranks > 1 && !b->comm)
+        return fail(HEAT_E_INVALID_ARG, "sharded batch without a communicator: call heat_batch_comm_init, or drive it "
+                                        "with heat_batch_step_surfaces / heat_batch_step_zones and your own collective");
     int rc = heat_batch_set_weather(b, weather, n_sub, zone_a0, zone_b0);
     if (rc) return rc;
+    if (b->comm && b->shared_set) {
+        // Sharded sub-timestep, everything in order on the batch's stream (no cross-queue dependency anywhere):
+        // this rank's surfaces -> zones only this rank touches finished, partial (a, b) of the shared zones ->
+        // RCCL all-gather of the [2][n_shared] blocks over xGMI -> shared zones updated from the blocks, summed
+        // in rank order (identical bits on every rank).
+        Rccl *r = rccl();
+        if (!r) return fail(HEAT_E_COMM, "RCCL is not loaded");
+        double *saved_partial = b->partial_ptr;
+        b->partial_ptr = b->d_partial.p;
+        for (int i = 0; i < n_sub; i++) {
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+            if (b->timing) {
+                e0 = next_event(b); e1 = next_event(b); e2 = next_event(b);
+                if (!e0 || !e1 || !e2) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
+                HIP_TRY(hipEventRecord(e0, b->stream));
+            }
+            enqueue_surfaces(b, i);
+            if (b->timing) HIP_TRY(hipEventRecord(e1, b->stream));
+            enqueue_zones(b, 2);
+            if (b->n_shared > 0) {
+                RCCL_TRY(r, r->AllGather(b->d_partial.p, b->d_gathered.p, (size_t)2 * b->n_shared, ncclDouble, b->comm,
+                                         b->stream));
+                launch_zone_update_shared(b->d_gathered.p, b->n_ranks, b->d_shared_zone.p, b->n_shared, b->d_zone_a0.p,
+                                          b->d_zone_b0.p, b->d_zone_vol.p, b->d_zone_T.p, b->dt, b->d_flags.p, b->stream);
+            }
+            if (b->timing) HIP_TRY(hipEventRecord(e2, b->stream));
+        }
+        b->partial_ptr = saved_partial;
+        HIP_TRY(hipGetLastError());
+        return HEAT_OK;
+    }
     if (b->timing) {
         for (int i = 0; i < n_sub; i++) {
             hipEvent_t e0 = next_event(b), e1 = next_event(b), e2 = next_event(b);

@@ -2,13 +2,25 @@
 
 Surfaces are independent inside a sub-timestep (reference src/model.rs:102-180); the only
 exchange is the zone heat balance ``a[z] = sum h A T_surf``, ``b[z] = sum h A`` over all surfaces
-touching zone z (src/model.rs:556-590). Each rank computes the partial sums of its own surfaces
-(``heat_batch_step_surfaces``). Zones that only one rank touches are finished right there; for the
-zones shared between ranks (agreed on once at setup) the partial blocks are all-gathered over
-RCCL/xGMI (``torch.distributed`` backend "nccl"; "gloo" on CPU in tests) and every rank applies the
-zone update from the blocks summed in rank order (``heat_batch_step_zones``) — so all replicas of a
-shared zone's temperature stay bitwise identical and the result does not depend on the collective's
-internal reduction order. A rank does not keep zones it never touches up to date.
+touching zone z (src/model.rs:556-590). Each rank computes the partial sums of its own surfaces.
+Zones that only one rank touches are finished right there; for the zones shared between ranks
+(agreed on once at setup) the partial blocks are all-gathered over RCCL/xGMI and every rank applies
+the zone update from the blocks summed in rank order — so all replicas of a shared zone's
+temperature stay bitwise identical and the result does not depend on the collective's internal
+reduction order. A rank does not keep zones it never touches up to date.
+
+Two ways to run the collective (``ShardedMarch(collective=...)``):
+
+``"native"`` (default on GPUs)
+    the library owns an RCCL communicator (``heat_batch_comm_init``; torch.distributed only carries
+    the 128-byte unique id to the ranks) and ``heat_batch_march_resident`` runs kernel -> ncclAllGather
+    -> kernel in ONE stream: no second queue, no cross-queue events, no Python per sub-timestep.
+    (Measured on MI355X: every dependency between two HIP streams costs 10-28 us even when it is
+    already satisfied — as much as the collective itself; see profiles/README.md.)
+``"torch"``
+    the split-phase C ABI (``heat_batch_step_surfaces`` / ``heat_batch_step_zones``) with
+    ``torch.distributed.all_gather_into_tensor`` in between ("nccl" on GPUs, "gloo" on CPU in tests):
+    for hosts that bring their own collective.
 """
 import numpy as np
 
@@ -71,9 +83,10 @@ def agree_on_shared_zones(local_mask, device, group=None):
 
 
 class ShardedMarch:
-    """Drives one rank's HeatBatch through the split-phase sub-timestep with the zone exchange."""
+    """Drives one rank's HeatBatch through the sharded sub-timestep with the zone exchange."""
 
-    def __init__(self, md_shard, rank, n_ranks, device_index=0, **batch_opts):
+    def __init__(self, md_shard, rank, n_ranks, device_index=0, collective="native", force_shared=None,
+                 **batch_opts):
         import sys
         from . import binding
         if binding._lib is not None and "torch" not in sys.modules:
@@ -81,25 +94,68 @@ class ShardedMarch:
                 "heat_amd: libheat_amd.so was loaded before torch; torch ships its own HIP runtime and the two "
                 "cannot share a device in one process. Import torch before creating the first HeatBatch.")
         import torch
-        from .binding import HeatBatch
+        import torch.distributed as dist
+        from .binding import HeatBatch, comm_unique_id
+        if collective not in ("native", "torch"):
+            raise ValueError("collective must be 'native' or 'torch'")
         self.torch = torch
+        self.collective = collective
+        self.n_ranks = n_ranks
         torch.cuda.set_device(device_index)
-        # A dedicated non-default stream: the library runs its kernels on it and torch orders the
-        # collective against it (the legacy default stream has handle 0, which the C ABI reads as
-        # "create your own stream").
+        dev = torch.device("cuda", device_index)
+        # A dedicated non-default stream: the library runs its kernels (and, natively, the collective) on it;
+        # torch orders its own collective against it (the legacy default stream has handle 0, which the C ABI
+        # reads as "create your own stream").
         self.stream = torch.cuda.Stream(device=device_index)
         self.batch = HeatBatch(md_shard, device=device_index, stream=self.stream.cuda_stream, n_ranks=n_ranks,
                                rank=rank, **batch_opts)
-        dev = torch.device("cuda", device_index)
-        self.shared = agree_on_shared_zones(self.batch.touched_zones(), dev)
-        self.batch.set_shared_zones(self.shared)
-        self.exchange = ZoneExchange(len(self.shared), dev)
-        self.batch.use_partials(self.exchange.partial.data_ptr())
-        self.n_ranks = n_ranks
+        if collective == "native":
+            # rank 0 draws the RCCL unique id; torch.distributed only carries its 128 bytes to the others
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                on_dev = dist.get_backend() == "nccl"
+                t = uid.to(dev) if on_dev else uid
+                dist.broadcast(t, src=0)
+                uid = t.cpu()
+            ok, why = 1, ""
+            try:
+                self.batch.comm_init(uid.numpy().tobytes())
+            except binding.HeatError as e:  # RCCL not loadable / communicator refused: every rank must learn of it
+                ok, why = 0, str(e)
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                t = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+            if not ok:
+                print("heat_amd: library-owned communicator unavailable (%s); using torch.distributed for the "
+                      "zone exchange" % (why or "another rank failed"), file=sys.stderr)
+                collective = self.collective = "torch"
+        if collective == "native":
+            self.shared = None  # agreed inside the library
+            if force_shared is not None:
+                self.batch.set_shared_zones(np.asarray(force_shared, dtype=np.int32))
+            self.exchange = None
+        else:
+            self.shared = agree_on_shared_zones(self.batch.touched_zones(), dev)
+            if force_shared is not None:
+                # tests / single-GPU rehearsal: treat these zones as shared although no other rank touches them
+                self.shared = np.union1d(self.shared, np.asarray(force_shared, dtype=np.int32)).astype(np.int32)
+            self.batch.set_shared_zones(self.shared)
+            self.exchange = ZoneExchange(len(self.shared), dev)
+            self.batch.use_partials(self.exchange.partial.data_ptr())
+
+    @property
+    def n_shared_zones(self):
+        return self.batch.n_shared_zones
 
     def march_resident(self, weather, zone_a0=None, zone_b0=None):
         """≙ ThermalModel::march on the device-resident state of this shard (asynchronous)."""
         b = self.batch
+        if self.collective == "native":
+            b.march_resident(weather, zone_a0, zone_b0)
+            return
         with self.torch.cuda.stream(self.stream):
             b.set_weather(weather, zone_a0, zone_b0)
             for i in range(len(weather)):

@@ -55,6 +55,7 @@ enum heat_status {
     HEAT_E_SIZE = -4,            /* slot or index out of range */
     HEAT_E_DEVICE = -5,          /* HIP runtime failure (message has the HIP error string) */
     HEAT_E_TOO_MANY_NODES = -6,
+    HEAT_E_COMM = -7,            /* RCCL not loadable, or a collective failed (message has RCCL's error string) */
     /* numerical failure on the device (reference: assert!/unreachable! panics) */
     HEAT_N_NAN_HS = 1,           /* surface.rs:704-707 */
     HEAT_N_NAN_NOMASS = 2,       /* surface.rs:850 */
@@ -138,7 +139,8 @@ typedef struct heat_batch_options {
     int32_t use_graph;       /* 1: replay the sub-timestep as a hipGraph inside heat_batch_march */
     void *stream;            /* hipStream_t to run on; NULL = a stream owned by the batch */
     /* Multi-GPU (one process per GPU): this rank holds a shard of the surfaces but all zones.
-     * With n_ranks > 1 heat_batch_march is unavailable; the caller alternates
+     * With n_ranks > 1 the caller either gives the batch a communicator (heat_batch_comm_init, below) and
+     * marches as on one GPU, or brings its own collective and alternates
      * heat_batch_step_surfaces -> all-gather of heat_batch_zone_partials -> heat_batch_step_zones. */
     int32_t n_ranks;
     int32_t rank;
@@ -196,6 +198,24 @@ int heat_batch_use_partials(heat_batch *b, double *partials_dev);
  * [block][2][n_shared], summed in block order. Zones this rank does not touch are not kept up to date on it. */
 int heat_batch_touched_zones(const heat_batch *b, uint8_t *mask);
 int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32_t n_shared);
+
+/*
+ * Library-owned collective (the default multi-GPU mode; one process per GPU): the batch holds an RCCL
+ * communicator and heat_batch_march_resident / heat_batch_march run the whole sharded sub-timestep on the batch's
+ * stream: surfaces -> zones only this rank touches + partial (a, b) of the shared ones -> ncclAllGather of the
+ * [2][n_shared] blocks over xGMI -> shared zones updated from the blocks summed in rank order. No torch, no second
+ * stream: a kernel, a collective and a kernel in one queue.
+ *   heat_comm_unique_id   ncclGetUniqueId; one rank calls it and the host program hands the bytes to every rank
+ *                         (any means: MPI, a file, torch.distributed's store, ...).
+ *   heat_batch_comm_init  ncclCommInitRank(n_ranks, rank of the batch's options) — collective: every rank calls it;
+ *                         then the ranks agree on the shared zones (an all-reduce of the touched masks) and the
+ *                         batch is switched to the compact exchange (as heat_batch_set_shared_zones does).
+ * RCCL is loaded at run time (dlopen "librccl.so.1"); without it both calls return HEAT_E_COMM.
+ */
+#define HEAT_COMM_ID_BYTES 128
+int heat_comm_unique_id(uint8_t id[HEAT_COMM_ID_BYTES]);
+int heat_batch_comm_init(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES]);
+int32_t heat_batch_n_shared_zones(const heat_batch *b);
 
 /* Introspection (tests, bench). */
 int64_t heat_batch_n_surfaces(const heat_batch *b);

@@ -28,20 +28,55 @@ def main():
     ref = st.copy()
     rc, _ = orc.OracleModel(md).march(ref, w)
     assert rc == 0
-    sm = ShardedMarch(md, 0, 1, device_index=0)
+    for collective in ("native", "torch"):
+        sm = ShardedMarch(md, 0, 1, device_index=0, collective=collective)
+        got = st.copy()
+        sm.batch.upload_state(got)
+        sm.march_resident(w[:3])
+        sm.march_resident(w[3:])
+        sm.synchronize()
+        sm.batch.download_state(got)
+        sm.close()
+        for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
+                    md["flow_back_slot"], md["zone_slot"]):
+            assert np.allclose(got[idx], ref[idx], rtol=1e-9, atol=1e-9)
+    forced_shared_zones_single_rank("native")
+    forced_shared_zones_single_rank("torch")
+    two_shards_on_one_gpu()
+    dist.destroy_process_group()
+    print("SHARDED OK")
+
+
+def forced_shared_zones_single_rank(collective):
+    """ShardedMarch end to end on one rank with some zones declared shared, so that the exchange really runs:
+    k_zones mode 2 -> all-gather of one block (native: ncclAllGather on the library's communicator inside
+    heat_batch_march_resident; torch: all_gather_into_tensor between the split-phase calls) -> k_zone_update_shared."""
+    md, st = mdl.ragged_mixed(3000, Z=12, dt=45.0, seed=5)
+    w = mdl.weather_series(9, 45.0)
+    a0 = np.linspace(0., 40., 12)
+    b0 = np.linspace(0., 2., 12)
+    ref = st.copy()
+    rc, iters = orc.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    sm = ShardedMarch(md, 0, 1, device_index=0, collective=collective, force_shared=[0, 5, 11])
+    assert sm.n_shared_zones == 3
     got = st.copy()
     sm.batch.upload_state(got)
-    sm.march_resident(w[:3])
-    sm.march_resident(w[3:])
+    sm.march_resident(w[:4], a0, b0)
+    sm.march_resident(w[4:], a0, b0)
     sm.synchronize()
+    assert sm.batch.nomass_iterations() == iters
     sm.batch.download_state(got)
+    # the whole-state march (upload inputs, march, download) works on a sharded batch too
+    got2 = st.copy()
+    sm.batch.upload_state(got2)
+    if collective == "native":
+        sm.batch.march(got2, w, a0, b0)
+        assert np.array_equal(got2, got)
     sm.close()
-    dist.destroy_process_group()
     for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
                 md["flow_back_slot"], md["zone_slot"]):
         assert np.allclose(got[idx], ref[idx], rtol=1e-9, atol=1e-9)
-    two_shards_on_one_gpu()
-    print("SHARDED OK")
 
 
 def two_shards_on_one_gpu():
