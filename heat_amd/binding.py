@@ -62,7 +62,7 @@ class Desc(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("force_general", C.c_int32), ("nodes_per_lane", C.c_int32),
                 ("use_graph", C.c_int32), ("stream", C.c_void_p), ("n_ranks", C.c_int32), ("rank", C.c_int32),
-                ("no_palette", C.c_int32), ("reserved", C.c_int32)]
+                ("no_palette", C.c_int32), ("no_fusion", C.c_int32)]
 
 
 class Layer(C.Structure):
@@ -102,6 +102,8 @@ SYMBOLS = [
     ("heat_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
     ("heat_batch_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("heat_batch_n_shared_zones", C.c_int32, [_H]),
+    ("heat_batch_set_fusion", C.c_int, [_H, C.c_int32]),
+    ("heat_batch_n_fused_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_nodes", C.c_int64, [_H]),
     ("heat_batch_n_zones", C.c_int64, [_H]),
@@ -231,7 +233,7 @@ class HeatBatch:
     """Device-resident batch of surfaces + zones (≙ ThermalModel, src/model.rs:54-77)."""
 
     def __init__(self, md, device=-1, force_general=False, nodes_per_lane=0, use_graph=False, stream=None,
-                 n_ranks=1, rank=0, no_palette=False):
+                 n_ranks=1, rank=0, no_palette=False, no_fusion=False):
         self._L = load_library()
         self._h = _H()
         desc, keep = make_desc(md)
@@ -244,6 +246,7 @@ class HeatBatch:
         opt.n_ranks = n_ranks
         opt.rank = rank
         opt.no_palette = 1 if no_palette else 0
+        opt.no_fusion = 1 if no_fusion else 0
         _check(self._L.heat_batch_create_ex(C.byref(desc), C.byref(opt), C.byref(self._h)))
         self.n_state = int(md["n_state"])
         self.n_zones = int(md["n_zones"])
@@ -339,6 +342,14 @@ class HeatBatch:
     @property
     def n_shared_zones(self):
         return int(self._L.heat_batch_n_shared_zones(self._h))
+
+    def set_fusion(self, enabled):
+        """Cluster-resident march on/off (off: every surface is streamed one sub-timestep per launch)."""
+        _check(self._L.heat_batch_set_fusion(self._h, 1 if enabled else 0))
+
+    @property
+    def n_fused_surfaces(self):
+        return int(self._L.heat_batch_n_fused_surfaces(self._h))
 
     def set_timing(self, enabled):
         _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -152,6 +153,20 @@ struct heat_batch {
     int64_t n_palette = 0;                      // surfaces whose constants are in palette form
 
     // layout
+    int64_t n_fused_surfaces = 0;
+    int n_stream_tiles[kNumFast] = {};  // tiles marched one sub-timestep per launch; the fused workgroups' tiles follow
+    // cluster-resident march: workgroups per class, in two width groups (<= 4 tiles, <= 8 tiles)
+    std::vector<FusedBlock> h_fblocks[kNumFast][2];
+    DevBuf<FusedBlock> d_fblocks[kNumFast][2];
+    DevBuf<int32_t> d_fzones, d_fzone_eoff;
+    DevBuf<uint16_t> d_fslots;
+    DevBuf<double> d_side_area;
+    DevBuf<int16_t> d_side_lzone;
+    std::vector<int32_t> h_zone_block;  // zone -> fused workgroup (global number) or -1
+    DevBuf<int32_t> d_stream_zones;     // zones whose balance is done by k_zones (not owned by a fused workgroup)
+    int n_stream_zones = 0;
+    bool any_fused = false;
+    hipEvent_t ev_fused = nullptr;
     int n_fast_tiles[kNumFast] = {};
     DevBuf<FastTile> d_fast_tiles[kNumFast];
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
@@ -213,6 +228,12 @@ struct heat_batch {
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    struct EvTriple { hipEvent_t e0, e1, e2; };            // one streamed sub-timestep: start, surfaces done, zones done
+    struct EvPair { hipEvent_t e0, e1; int n_sub; };       // one cluster-resident launch over n_sub sub-timesteps
+    std::vector<EvTriple> ev_triples;
+    std::vector<EvPair> ev_fused_pairs;
+    bool fusion_on = true;     // heat_batch_options::no_fusion / heat_batch_set_fusion
+    bool graph_fused = false;  // what the captured sub-timestep graph leaves out
 
     ~heat_batch() {
         if (comm) {
@@ -229,6 +250,7 @@ struct heat_batch {
             if (side[i]) (void)hipStreamDestroy(side[i]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_fused) (void)hipEventDestroy(ev_fused);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -240,13 +262,31 @@ struct Placed {
     int n;       // node count
     int cls;     // 0..kNumFast-1 fast classes, kGeneral = catch-all
     int k;       // lanes per surface (fast)
+    int blk;     // cluster-resident march: workgroup number, -1 = streamed
+};
+
+// Tiles a set of fast-path surfaces needs: surfaces of equal k share a tile, floor(64 / k) per tile.
+int tiles_needed(const int (&cnt)[kWave + 1]) {
+    int t = 0;
+    for (int k = 1; k <= kWave; k++)
+        if (cnt[k]) t += (cnt[k] + kWave / k - 1) / (kWave / k);
+    return t;
+}
+
+// What kind of kernel a surface needs (before the blocking factor M is chosen).
+struct Category {
+    int kind;  // kSmall, kSmallCav, kGeneral, or 0 = fast path
+    int nm;    // fast: has a no-mass facing node
+    int ncav;  // fast: gas cavities between massive nodes
+    int pal;   // fast: the per-node constants fit a palette
 };
 
 // Decides whether a surface can take the register-resident fast path:
 // solid conductances only, solar absorbed at the two faces only, every interior node massive; the
 // face nodes may be no-mass facings (each then is an isolated one-node no-mass chunk).
-int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
-    if (opt.force_general) return kGeneral;
+Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
+    Category r{kGeneral, 0, 0, 0};
+    if (opt.force_general) return r;
     const int64_t o = d->node_offset[s];
     if (n <= 4) {
         bool all_nomass = true;
@@ -254,42 +294,29 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
         bool has_cav = false;
         for (int i = 0; i < n; i++)
             has_cav = has_cav || (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0);
-        if (all_nomass) return has_cav ? kSmallCav : kSmall;
+        if (all_nomass) {
+            r.kind = has_cav ? kSmallCav : kSmall;
+            return r;
+        }
     }
-    if (n < 2) return kGeneral;
+    if (n < 2) return r;
     int nm = 0, ncav = 0;
     auto is_cav = [&](int i) { return d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0; };
     for (int i = 0; i < n; i++) {
         if (d->mass[o + i] < kMassThreshold) {
-            if (i != 0 && i != n - 1) return kGeneral;                        // no-mass node inside
+            if (i != 0 && i != n - 1) return r;                        // no-mass node inside
             nm = 1;
         }
         if (is_cav(i)) {
             // a cavity on the fast path sits between two massive nodes (its conductance is then needed
             // once per sub-timestep, not once per pass of a no-mass loop)
-            if (i + 1 >= n || d->mass[o + i] < kMassThreshold || d->mass[o + i + 1] < kMassThreshold) return kGeneral;
-            if (++ncav > 2) return kGeneral;
+            if (i + 1 >= n || d->mass[o + i] < kMassThreshold || d->mass[o + i + 1] < kMassThreshold) return r;
+            if (++ncav > 2) return r;
         }
-        if (i > 0 && d->front_alpha[o + i] != 0.0) return kGeneral;           // solar absorbed inside
-        if (i < n - 1 && d->back_alpha[o + i] != 0.0) return kGeneral;
+        if (i > 0 && d->front_alpha[o + i] != 0.0) return r;           // solar absorbed inside
+        if (i < n - 1 && d->back_alpha[o + i] != 0.0) return r;
     }
-    if (n == 2 && d->mass[o] < kMassThreshold && d->mass[o + 1] < kMassThreshold) return kGeneral;  // 2-node chunk
-    int M = opt.nodes_per_lane;
-    if (M == 0) {
-        // Nodes are padded to a multiple of M inside the last lane. Measured cost per padded node
-        // (1 M x 32 and 1 M x 20 nodes, profiles/README.md): M = 16 : 8 : 4 = 1.00 : 1.03 : 1.30 — larger blocks
-        // amortise the per-surface boundary work over more nodes. Pick the cheapest.
-        const double w[3] = {1.30, 1.03, 1.00};
-        const int ms[3] = {4, 8, 16};
-        double best = 0.0;
-        for (int q = 0; q < 3; q++) {
-            const int padded = (n + ms[q] - 1) / ms[q] * ms[q];
-            const double cost = padded * w[q];
-            if (M == 0 || cost < best) { M = ms[q]; best = cost; }
-        }
-    }
-    const int k = (n + M - 1) / M;
-    if (k > kWave) return kGeneral;
+    if (n == 2 && d->mass[o] < kMassThreshold && d->mass[o + 1] < kMassThreshold) return r;  // 2-node chunk
     // Palette form when the wall has few distinct constants (entry 0 of each palette is 0.0).
     int pal = opt.no_palette ? 0 : 1;
     if (pal) {
@@ -309,9 +336,31 @@ int classify(const heat_batch_desc *d, int64_t s, int n, const heat_batch_option
             if (f < 0) { if (nu == kPalU) pal = 0; else uu[nu++] = u; }
         }
     }
-    if (ncav > 0 && !pal) return kGeneral;  // the cavity variant exists in palette form only
-    return (M == 4 ? 0 : (M == 8 ? 6 : 12)) + nm * 3 + (ncav > 0 ? 2 : pal);
+    if (ncav > 0 && !pal) return r;  // the cavity variant exists in palette form only
+    r.kind = 0;
+    r.nm = nm;
+    r.ncav = ncav;
+    r.pal = pal;
+    return r;
 }
+
+// Nodes are padded to a multiple of M inside the last lane. Measured cost per padded node
+// (1 M x 32 and 1 M x 20 nodes, profiles/README.md): M = 16 : 8 : 4 = 1.00 : 1.03 : 1.30 — larger blocks
+// amortise the per-surface boundary work over more nodes.
+double padded_cost(int n, int M) {
+    const double w = (M == 4) ? 1.30 : (M == 8 ? 1.03 : 1.00);
+    return (double)((n + M - 1) / M * M) * w;
+}
+
+int choose_M(int n, const heat_batch_options &opt) {
+    if (opt.nodes_per_lane != 0) return opt.nodes_per_lane;
+    int M = 4;
+    for (int m : {8, 16})
+        if (padded_cost(n, m) < padded_cost(n, M)) M = m;
+    return M;
+}
+
+int fast_class(int M, const Category &c) { return (M == 4 ? 0 : (M == 8 ? 6 : 12)) + c.nm * 3 + (c.ncav > 0 ? 2 : c.pal); }
 
 int check_desc(const heat_batch_desc *d) {
     if (!d) return fail(HEAT_E_INVALID_ARG, "descriptor is NULL");
@@ -391,21 +440,177 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     b->n_nodes = S > 0 ? d->node_offset[S] : 0;
     b->algorithmic_bytes = 32 * b->n_nodes + 152 * S;  // 32 n + 152 bytes per surface per sub-timestep
 
-    // ---- classify and order ----
+    // ---- classify ----
     std::vector<Placed> placed(S);
+    std::vector<Category> cat(S);
     for (int64_t s = 0; s < S; s++) {
         const int n = (int)(d->node_offset[s + 1] - d->node_offset[s]);
-        const int cls = classify(d, s, n, opt);
-        const int M = cls < kNumFast ? kFastM[cls] : 0;
-        placed[s] = Placed{s, n, cls, cls < kNumFast ? (n + M - 1) / M : 1};
+        cat[s] = categorize(d, s, n, opt);
+        int cls = cat[s].kind, k = 1;
+        if (cat[s].kind == 0) {
+            const int M = choose_M(n, opt);
+            k = (n + M - 1) / M;
+            cls = (k > kWave) ? kGeneral : fast_class(M, cat[s]);
+            if (k > kWave) { cat[s].kind = kGeneral; k = 1; }
+        }
+        placed[s] = Placed{s, n, cls, k, -1};
+    }
+
+    // ---- cluster-resident march: zone-connected clusters -> workgroups (layout.hpp, FusedBlock) ----
+    // A cluster is a connected component of the graph "zone - surface facing it"; its surfaces exchange heat
+    // only through its own zones (model.rs:556-590), so a workgroup that holds all of them can march any number
+    // of sub-timesteps without leaving the chip. A cluster is fused when every surface of it is a palette-form
+    // fast-path wall without cavities and it fits kFusedMaxWaves tiles / kFusedMaxZones zones; its surfaces then
+    // share one blocking factor (4 or 8: the 16-node variant does not fit the register file with the state that
+    // lives across sub-timesteps). Surfaces that face no zone at all are clusters of one and are packed freely.
+    struct BlockPlan { int cls; std::vector<int32_t> zones; };
+    std::vector<BlockPlan> blocks;
+    const bool fuse = !opt.no_fusion && !opt.force_general && !opt.no_palette &&
+                      (opt.nodes_per_lane == 0 || opt.nodes_per_lane == 4 || opt.nodes_per_lane == 8);
+    if (fuse && S > 0) {
+        auto fusable = [&](int64_t s) { return cat[s].kind == 0 && cat[s].pal && cat[s].ncav == 0; };
+        auto zone_of_side = [&](int64_t s, int side) -> int32_t {
+            const int kind = side ? d->back_kind[s] : d->front_kind[s];
+            return kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
+        };
+        std::vector<int32_t> uf(Z);
+        std::iota(uf.begin(), uf.end(), 0);
+        auto find = [&](int32_t x) {
+            while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; }
+            return x;
+        };
+        for (int64_t s = 0; s < S; s++) {
+            const int32_t zf = zone_of_side(s, 0), zb = zone_of_side(s, 1);
+            if (zf >= 0 && zb >= 0) {
+                const int32_t a = find(zf), c = find(zb);
+                if (a != c) uf[std::max(a, c)] = std::min(a, c);
+            }
+        }
+        // per cluster (root zone): its surfaces (CSR), whether all of them are fusable
+        std::vector<int64_t> coff(Z + 1, 0);
+        std::vector<uint8_t> cok(Z, 1);
+        auto root_of = [&](int64_t s) -> int32_t {
+            const int32_t zf = zone_of_side(s, 0), zb = zone_of_side(s, 1);
+            return zf >= 0 ? find(zf) : (zb >= 0 ? find(zb) : -1);
+        };
+        std::vector<int32_t> sroot(S);
+        for (int64_t s = 0; s < S; s++) {
+            sroot[s] = root_of(s);
+            if (sroot[s] >= 0) {
+                coff[sroot[s] + 1]++;
+                if (!fusable(s)) cok[sroot[s]] = 0;
+            }
+        }
+        for (int64_t z = 0; z < Z; z++) coff[z + 1] += coff[z];
+        std::vector<int64_t> csurf(Z > 0 ? coff[Z] : 0), ccur(coff.begin(), coff.end() - 1);
+        for (int64_t s = 0; s < S; s++)
+            if (sroot[s] >= 0) csurf[ccur[sroot[s]]++] = s;
+        std::vector<std::vector<int32_t>> czones(Z);  // zones of each root
+        for (int64_t z = 0; z < Z; z++) czones[find((int32_t)z)].push_back((int32_t)z);
+
+        // open workgroup per class: surfaces per k, zones so far
+        struct Open { int blk = -1; int cnt[kWave + 1] = {}; int nz = 0; int ne = 0; };
+        Open open[kNumFast];
+        auto new_block = [&](int cls) {
+            blocks.push_back(BlockPlan{cls, {}});
+            return (int)blocks.size() - 1;
+        };
+        const int ms_all[2] = {4, 8};
+        for (int64_t r = 0; r < Z; r++) {
+            if (find((int32_t)r) != r || !cok[r] || coff[r + 1] == coff[r]) continue;
+            // one blocking factor for the cluster: the cheaper of 4 and 8 nodes per lane
+            int M = opt.nodes_per_lane;
+            if (M == 0) {
+                double best = 0.0;
+                for (int m : ms_all) {
+                    double c = 0.0;
+                    for (int64_t q = coff[r]; q < coff[r + 1]; q++) c += padded_cost(placed[csurf[q]].n, m);
+                    if (M == 0 || c < best) { M = m; best = c; }
+                }
+            }
+            int nm = 0, cnt[kWave + 1] = {}, ne = 0;
+            bool fits = true;
+            for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                const Placed &pl = placed[csurf[q]];
+                const int k = (pl.n + M - 1) / M;
+                if (k > kWave || k < 2) { fits = false; break; }  // (the fused kernels have no single-lane path)
+                cnt[k]++;
+                nm |= cat[csurf[q]].nm;
+                ne += (zone_of_side(csurf[q], 0) >= 0) + (zone_of_side(csurf[q], 1) >= 0);
+            }
+            const int nz = (int)czones[r].size();
+            if (!fits || tiles_needed(cnt) > kFusedMaxWaves || nz > kFusedMaxZones || ne > kFusedMaxEntries) continue;  // streamed
+            Category cc{0, nm, 0, 1};
+            const int cls = fast_class(M, cc);
+            Open &o = open[cls];
+            int merged[kWave + 1];
+            for (int k = 0; k <= kWave; k++) merged[k] = o.cnt[k] + cnt[k];
+            if (o.blk < 0 || tiles_needed(merged) > kFusedMaxWaves || o.nz + nz > kFusedMaxZones ||
+                o.ne + ne > kFusedMaxEntries) {
+                o = Open();
+                o.blk = new_block(cls);
+                for (int k = 0; k <= kWave; k++) merged[k] = cnt[k];
+            }
+            for (int k = 0; k <= kWave; k++) o.cnt[k] = merged[k];
+            o.nz += nz;
+            o.ne += ne;
+            for (int32_t z : czones[r]) blocks[o.blk].zones.push_back(z);
+            for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                Placed &pl = placed[csurf[q]];
+                pl.cls = cls;
+                pl.k = (pl.n + M - 1) / M;
+                pl.blk = o.blk;
+            }
+        }
+        // surfaces that face no zone: any grouping will do; workgroups of up to 4 tiles of equal k
+        for (int c = 0; c < kNumFast; c++) open[c] = Open();
+        std::vector<int64_t> lone;
+        std::vector<uint8_t> lone_ok(S, 1);
+        for (int64_t s = 0; s < S; s++)
+            if (sroot[s] < 0 && fusable(s)) lone.push_back(s);
+        for (int64_t s : lone) {
+            Placed &pl = placed[s];
+            int M = opt.nodes_per_lane;
+            if (M == 0) M = padded_cost(pl.n, 8) < padded_cost(pl.n, 4) ? 8 : 4;
+            int k = (pl.n + M - 1) / M;
+            if (k < 2 && opt.nodes_per_lane == 0 && pl.n > 4) { M = 4; k = (pl.n + M - 1) / M; }
+            if (k > kWave || k < 2) { lone_ok[s] = 0; continue; }
+            pl.cls = fast_class(M, Category{0, cat[s].nm, 0, 1});
+            pl.k = k;
+        }
+        std::stable_sort(lone.begin(), lone.end(), [&](int64_t x, int64_t y) {
+            if (placed[x].cls != placed[y].cls) return placed[x].cls < placed[y].cls;
+            return placed[x].k < placed[y].k;
+        });
+        {
+            int cur_cls = -1, cur_k = -1, cur_blk = -1, in_blk = 0;
+            for (int64_t s : lone) {
+                Placed &pl = placed[s];
+                if (!lone_ok[s] || pl.cls >= kNumFast) continue;
+                const int cap = 4 * (kWave / pl.k);
+                if (pl.cls != cur_cls || pl.k != cur_k || in_blk >= cap) {
+                    cur_cls = pl.cls; cur_k = pl.k; in_blk = 0;
+                    cur_blk = new_block(pl.cls);
+                }
+                pl.blk = cur_blk;
+                in_blk++;
+            }
+        }
+    }
+    for (int64_t s = 0; s < S; s++) {
+        const int cls = placed[s].cls;
         b->class_counts[cls < kNumFast ? cls / 6 : (cls < kGeneral ? 3 : 4)]++;
         if (cls < kNumFast && kFastPAL[cls]) b->n_palette++;
+        if (placed[s].blk >= 0) b->n_fused_surfaces++;
     }
+
+    // ---- order: class, then streamed surfaces before the fused workgroups, then lanes per surface ----
     std::vector<int64_t> order(S);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
         const Placed &a = placed[x], &c = placed[y];
         if (a.cls != c.cls) return a.cls < c.cls;
+        if (a.blk != c.blk) return a.blk < c.blk;
         if (a.cls < kNumFast) return a.k < c.k;
         return a.n < c.n;
     });
@@ -419,7 +624,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     int64_t node_cursor = 0, scratch_cursor = 0;
     int64_t dcur = 0;
     size_t pos = 0;
-    struct NodeMap { int64_t base; int Lk; int k; int M; int g; };  // per device surface
+    struct NodeMap { int64_t base; int Lk; int k; int M; int g; int tile; };  // per device surface
+    std::vector<int> blk_first_tile(blocks.size(), -1), blk_n_tiles(blocks.size(), 0);
     std::vector<NodeMap> nmap(S);
     int prev_cls = -1;
     while (pos < (size_t)S) {
@@ -431,7 +637,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             const int Gmax = kWave / k, Lk = Gmax * k;
             size_t end = pos;
             while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].k == k &&
-                   (int)(end - pos) < Gmax)
+                   placed[order[end]].blk == p0.blk && (int)(end - pos) < Gmax)
                 end++;
             bool all_full = true;
             for (size_t q = pos; q < end; q++) all_full = all_full && (placed[order[q]].n == k * M);
@@ -440,12 +646,19 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             t.surf_base = (int32_t)dcur;
             t.k = (int16_t)(k | (all_full ? 0x100 : 0));
             t.G = (int16_t)(end - pos);
+            const int tile_index = (int)fast_tiles[p0.cls].size();
             fast_tiles[p0.cls].push_back(t);
+            if (p0.blk >= 0) {
+                if (blk_first_tile[p0.blk] < 0) blk_first_tile[p0.blk] = tile_index;
+                blk_n_tiles[p0.blk]++;
+            } else {
+                b->n_stream_tiles[p0.cls] = tile_index + 1;  // streamed tiles come first in every class
+            }
             for (size_t q = pos; q < end; q++) {
                 const int64_t s = order[q];
                 dev_of[s] = dcur;
                 orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, Lk, k, M, (int)(q - pos)};
+                nmap[dcur] = NodeMap{node_cursor, Lk, k, M, (int)(q - pos), tile_index};
                 dcur++;
             }
             node_cursor += (int64_t)M * Lk;
@@ -470,7 +683,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 const int64_t s = order[q];
                 dev_of[s] = dcur;
                 orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos)};
+                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos), 0};
                 dcur++;
             }
             node_cursor += (int64_t)n_max * kWave;
@@ -616,6 +829,81 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         }
     }
 
+    // ---- cluster-resident march: workgroup tables ----
+    std::vector<int32_t> fz, fz_eoff(1, 0);
+    std::vector<uint16_t> fent;
+    std::vector<double> side_area(2 * S, 0.0);
+    std::vector<int16_t> side_lz(2 * S, -1);
+    b->h_zone_block.assign(Z, -1);
+    b->any_fused = false;
+    if (!blocks.empty()) {
+        std::vector<int32_t> lz_of_zone(Z, -1);
+        std::vector<int> blk_fw(blocks.size(), 4);
+        std::vector<int32_t> blk_first_zone(blocks.size(), 0);
+        for (size_t bi = 0; bi < blocks.size(); bi++) {
+            if (blk_n_tiles[bi] <= 0) continue;  // (an empty plan: cannot happen, kept harmless)
+            blk_fw[bi] = blk_n_tiles[bi] <= 4 ? 4 : 8;
+            blk_first_zone[bi] = (int32_t)fz.size();
+            for (size_t j = 0; j < blocks[bi].zones.size(); j++) {
+                const int32_t z = blocks[bi].zones[j];
+                lz_of_zone[z] = (int32_t)j;
+                b->h_zone_block[z] = (int32_t)bi;
+                fz.push_back(z);
+            }
+        }
+        // contributions in the reference's order inside each zone (model.rs:562-585): counting sort by fused zone
+        std::vector<int32_t> fz_index(Z, -1);
+        for (size_t i = 0; i < fz.size(); i++) fz_index[fz[i]] = (int32_t)i;
+        std::vector<int32_t> cnt(fz.size() + 1, 0);
+        auto side_zone = [&](int64_t s, int side) -> int32_t {
+            const int kind = side ? d->back_kind[s] : d->front_kind[s];
+            const int32_t z = kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
+            return (z >= 0 && placed[s].blk >= 0) ? z : -1;
+        };
+        for (int64_t s = 0; s < S; s++)
+            for (int side = 0; side < 2; side++) {
+                const int32_t z = side_zone(s, side);
+                if (z >= 0) cnt[fz_index[z] + 1]++;
+            }
+        for (size_t i = 0; i < fz.size(); i++) cnt[i + 1] += cnt[i];
+        fz_eoff.assign(cnt.begin(), cnt.end());
+        fent.resize(cnt[fz.size()]);
+        std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (int64_t s = 0; s < S; s++)
+            for (int side = 0; side < 2; side++) {
+                const int32_t z = side_zone(s, side);
+                if (z < 0) continue;
+                const int bi = placed[s].blk;
+                const NodeMap &m = nmap[dev_of[s]];
+                const int lane = side ? (m.g * m.k + m.k - 1) : (m.g * m.k);
+                const uint32_t slot = (uint32_t)(side * kWave * blk_fw[bi] + (m.tile - blk_first_tile[bi]) * kWave + lane);
+                fent[cur[fz_index[z]]++] = (uint16_t)slot;
+                side_lz[(int64_t)side * S + dev_of[s]] = (int16_t)lz_of_zone[z];
+            }
+        for (size_t bi = 0; bi < blocks.size(); bi++) {
+            if (blk_n_tiles[bi] <= 0) continue;
+            FusedBlock fb{blk_first_tile[bi], blk_n_tiles[bi], blk_first_zone[bi], (int32_t)blocks[bi].zones.size()};
+            b->h_fblocks[blocks[bi].cls][blk_fw[bi] == 4 ? 0 : 1].push_back(fb);
+            b->any_fused = true;
+        }
+    }
+    {
+        std::vector<int32_t> sz;
+        for (int64_t z = 0; z < Z; z++) if (b->h_zone_block[z] < 0) sz.push_back((int32_t)z);
+        b->n_stream_zones = (int)sz.size();
+        HIP_TRY(b->d_stream_zones.upload(sz));
+    }
+    for (int c = 0; c < kNumFast; c++) {
+        if (b->h_fblocks[c][0].empty() && b->h_fblocks[c][1].empty()) b->n_stream_tiles[c] = (int)fast_tiles[c].size();
+        for (int g2 = 0; g2 < 2; g2++) HIP_TRY(b->d_fblocks[c][g2].upload(b->h_fblocks[c][g2]));
+    }
+    HIP_TRY(b->d_fzones.upload(fz));
+    HIP_TRY(b->d_fzone_eoff.upload(fz_eoff));
+    for (int64_t dd = 0; dd < S; dd++) side_area[dd] = side_area[S + dd] = d->area[orig_of[dd]];
+    HIP_TRY(b->d_fslots.upload(fent));
+    HIP_TRY(b->d_side_area.upload(side_area));
+    HIP_TRY(b->d_side_lzone.upload(side_lz));
+
     // zones this batch's surfaces touch (for sharded batches)
     b->h_touched.assign(Z, 0);
     for (int64_t z = 0; z < Z; z++) b->h_touched[z] = zoff[z + 1] > zoff[z] ? 1 : 0;
@@ -718,13 +1006,16 @@ int select_device(heat_batch *b) {
     return HEAT_OK;
 }
 
-// iterate_surfaces for every group (model.rs:388-408)
-void enqueue_surfaces(heat_batch *b, int step_fixed) {
+// iterate_surfaces for every group (model.rs:388-408), one sub-timestep.
+// streamed_only: leave out the tiles owned by the cluster-resident march (enqueue_fused marches those).
+void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false) {
+    int nt[kNumFast];
+    for (int c = 0; c < kNumFast; c++) nt[c] = streamed_only ? b->n_stream_tiles[c] : b->n_fast_tiles[c];
     // The classes are independent (model.rs:102-180: surfaces never read what another surface wrote in the
     // same sub-timestep): spread them over the batch's stream and its side streams so that one class's
     // tail overlaps the next class's head.
     int n_launch = 0;
-    for (int c = 0; c < kNumFast; c++) n_launch += b->n_fast_tiles[c] > 0;
+    for (int c = 0; c < kNumFast; c++) n_launch += nt[c] > 0;
     n_launch += b->n_small_plain_tiles > 0;
     n_launch += b->n_small_tiles > b->n_small_plain_tiles;
     n_launch += b->n_gen_tiles > b->n_small_tiles;
@@ -744,19 +1035,19 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
     // work of each class in node slots, to size the persistent grids
     double work[kNumFast], total_work = 0.0;
     for (int c = 0; c < kNumFast; c++) {
-        work[c] = (double)b->n_fast_tiles[c] * kFastM[c];
+        work[c] = (double)nt[c] * kFastM[c];
         total_work += work[c];
     }
     total_work += 2.0 * b->n_gen_tiles;  // small / general tiles: a few nodes per lane
     // biggest classes first
     int order[kNumFast];
     for (int c = 0; c < kNumFast; c++) order[c] = c;
-    std::sort(order, order + kNumFast, [&](int x, int y) { return b->n_fast_tiles[x] > b->n_fast_tiles[y]; });
+    std::sort(order, order + kNumFast, [&](int x, int y) { return nt[x] > nt[y]; });
     for (int q = 0; q < kNumFast; q++) {
         const int c = order[q];
-        if (b->n_fast_tiles[c] <= 0) continue;
+        if (nt[c] <= 0) continue;
         launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], kFastCAV[c], work[c] / total_work,
-                             b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
+                             b->d_fast_tiles[c].p, nt[c], b->na,
                              b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
                              b->d_nomass_iters.p + b->nm_count_base[c], next_stream());
     }
@@ -784,10 +1075,43 @@ void enqueue_surfaces(heat_batch *b, int step_fixed) {
     }
 }
 
+// mode 0 / 1 / 2 as k_zones; mode 3: as mode 0 (full update, advances the step counter) but only the zones no
+// fused workgroup owns (the cluster-resident march balances its own zones in LDS).
 void enqueue_zones(heat_batch *b, int mode) {
+    const int32_t *zl = b->d_zlist.p;
+    int nl = b->n_touched;
+    if (mode == 3) { zl = b->d_stream_zones.p; nl = b->n_stream_zones; }
     launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_side_out.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
-                 b->d_flags.p, mode, b->d_zlist.p, b->n_touched, b->d_slot_of.p, b->n_shared, b->stream);
+                 b->d_flags.p, mode, zl, nl, b->d_slot_of.p, b->n_shared, b->stream);
+}
+
+// The cluster-resident march: every fused workgroup marches n_sub sub-timesteps in one launch per class.
+int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
+    FusedArgs fa{};
+    fa.zones = b->d_fzones.p;
+    fa.zone_eoff = b->d_fzone_eoff.p;
+    fa.slots = b->d_fslots.p;
+    fa.side_area = b->d_side_area.p;
+    fa.side_lzone = b->d_side_lzone.p;
+    fa.a0 = b->d_zone_a0.p;
+    fa.b0 = b->d_zone_b0.p;
+    fa.vol = b->d_zone_vol.p;
+    fa.zone_T = b->d_zone_T.p;
+    fa.dt = b->dt;
+    fa.n_sub = n_sub;
+    static const int dbg = getenv("HEAT_AMD_FUSED_DEBUG") ? atoi(getenv("HEAT_AMD_FUSED_DEBUG")) : 0;
+    fa.pad = dbg;  // timing experiments only (results are wrong with any bit set): 1 no zone math, 2 no zone sums, 4 no barriers
+    for (int c = 0; c < kNumFast; c++)
+        for (int g2 = 0; g2 < 2; g2++) {
+            const int nb = (int)b->h_fblocks[c][g2].size();
+            if (nb == 0) continue;
+            fa.blocks = b->d_fblocks[c][g2].p;
+            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], g2 ? 8 : 4, nb, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
+                                          b->na, b->sa, b->d_weather.p, b->d_flags.p,
+                                          b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
+        }
+    return HEAT_OK;
 }
 
 hipEvent_t next_event(heat_batch *b) {
@@ -842,6 +1166,7 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
     b->n_ranks = opt.n_ranks;
     b->rank = opt.rank;
     b->use_graph = opt.use_graph != 0;
+    b->fusion_on = opt.no_fusion == 0;
     rc = select_device(b);
     if (!rc) {
         if (opt.stream) {
@@ -858,7 +1183,8 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
                 hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess)
                 rc = fail(HEAT_E_DEVICE, "side stream creation failed");
         }
-        if (!rc && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess)
+        if (!rc && (hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&b->ev_fused, hipEventDisableTiming) != hipSuccess))
             rc = fail(HEAT_E_DEVICE, "event creation failed");
     }
     if (!rc) rc = build(b, desc, opt);
@@ -998,7 +1324,10 @@ int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step) {
     enqueue_surfaces(b, sub_step);
     if (b->timing) HIP_TRY(hipEventRecord(e1, b->stream));
     enqueue_zones(b, b->shared_set ? 2 : 1);  // partial (a, b) of this rank's surfaces
-    if (b->timing) HIP_TRY(hipEventRecord(e2, b->stream));
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(e2, b->stream));
+        b->ev_triples.push_back({e0, e1, e2});
+    }
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
 }
@@ -1128,37 +1457,78 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
                 launch_zone_update_shared(b->d_gathered.p, b->n_ranks, b->d_shared_zone.p, b->n_shared, b->d_zone_a0.p,
                                           b->d_zone_b0.p, b->d_zone_vol.p, b->d_zone_T.p, b->dt, b->d_flags.p, b->stream);
             }
-            if (b->timing) HIP_TRY(hipEventRecord(e2, b->stream));
+            if (b->timing) {
+                HIP_TRY(hipEventRecord(e2, b->stream));
+                b->ev_triples.push_back({e0, e1, e2});
+            }
         }
         b->partial_ptr = saved_partial;
         HIP_TRY(hipGetLastError());
         return HEAT_OK;
     }
-    if (b->timing) {
+    // Cluster-resident march: the fused workgroups march all n_sub sub-timesteps in one launch per class (on a
+    // side stream when other surfaces are streamed beside them); whatever is not fused is streamed as before.
+    const bool fused = b->any_fused && b->fusion_on && n_sub > 0;
+    bool streamed = !fused;
+    if (fused) {
+        for (int c = 0; c < kNumFast; c++) streamed = streamed || b->n_stream_tiles[c] > 0;
+        streamed = streamed || b->n_gen_tiles > 0 || b->n_stream_zones > 0;
+    }
+    hipStream_t fs = b->stream;
+    if (fused) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (streamed && b->side[2] != nullptr) {
+            fs = b->side[2];
+            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+            HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
+        }
+        if (b->timing) {
+            e0 = next_event(b); e1 = next_event(b);
+            if (!e0 || !e1) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e0, fs));
+        }
+        rc = enqueue_fused(b, n_sub, fs);
+        if (rc) return rc;
+        if (b->timing) {
+            HIP_TRY(hipEventRecord(e1, fs));
+            b->ev_fused_pairs.push_back({e0, e1, n_sub});
+        }
+    }
+    const int zmode = fused ? 3 : 0;
+    if (!streamed) {
+        // nothing to stream
+    } else if (b->timing) {
         for (int i = 0; i < n_sub; i++) {
             hipEvent_t e0 = next_event(b), e1 = next_event(b), e2 = next_event(b);
             if (!e0 || !e1 || !e2) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(e0, b->stream));
-            enqueue_surfaces(b, -1);
+            enqueue_surfaces(b, -1, fused);
             HIP_TRY(hipEventRecord(e1, b->stream));
-            enqueue_zones(b, 0);
+            enqueue_zones(b, zmode);
             HIP_TRY(hipEventRecord(e2, b->stream));
+            b->ev_triples.push_back({e0, e1, e2});
         }
     } else if (b->use_graph) {
-        if (!b->graph_exec) {
+        if (!b->graph_exec || b->graph_fused != fused) {
+            if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
             if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
             HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_surfaces(b, -1);
-            enqueue_zones(b, 0);
+            enqueue_surfaces(b, -1, fused);
+            enqueue_zones(b, zmode);
             HIP_TRY(hipStreamEndCapture(b->stream, &b->graph));
             HIP_TRY(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+            b->graph_fused = fused;
         }
         for (int i = 0; i < n_sub; i++) HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
     } else {
         for (int i = 0; i < n_sub; i++) {
-            enqueue_surfaces(b, -1);
-            enqueue_zones(b, 0);
+            enqueue_surfaces(b, -1, fused);
+            enqueue_zones(b, zmode);
         }
+    }
+    if (fused && fs != b->stream) {
+        HIP_TRY(hipEventRecord(b->ev_fused, fs));
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fused, 0));
     }
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
@@ -1206,6 +1576,8 @@ int heat_batch_set_timing(heat_batch *b, int32_t enabled) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
     b->timing = enabled != 0;
     b->ev_used = 0;
+    b->ev_triples.clear();
+    b->ev_fused_pairs.clear();
     return HEAT_OK;
 }
 
@@ -1214,20 +1586,42 @@ int heat_batch_get_timing(heat_batch *b, double *surf_us, double *substep_us, in
     int rc = select_device(b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
-    double s_surf = 0, s_all = 0;
-    const size_t n = b->ev_used / 3;
-    for (size_t i = 0; i < n; i++) {
+    double s_surf = 0, s_all = 0, s_fused = 0;
+    int64_t n_fused_steps = 0;
+    const size_t n = b->ev_triples.size();
+    for (const auto &t : b->ev_triples) {
         float ms1 = 0, ms2 = 0;
-        HIP_TRY(hipEventElapsedTime(&ms1, b->ev_pool[3 * i], b->ev_pool[3 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&ms2, b->ev_pool[3 * i], b->ev_pool[3 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&ms1, t.e0, t.e1));
+        HIP_TRY(hipEventElapsedTime(&ms2, t.e0, t.e2));
         s_surf += ms1;
         s_all += ms2;
     }
-    if (surf_us) *surf_us = n ? s_surf * 1000.0 / (double)n : 0.0;
-    if (substep_us) *substep_us = n ? s_all * 1000.0 / (double)n : 0.0;
-    if (n_samples) *n_samples = (int64_t)n;
+    for (const auto &p : b->ev_fused_pairs) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.e0, p.e1));
+        s_fused += ms;
+        n_fused_steps += p.n_sub;
+    }
+    const double stream_surf = n ? s_surf * 1000.0 / (double)n : 0.0;
+    const double stream_all = n ? s_all * 1000.0 / (double)n : 0.0;
+    const double fused_us = n_fused_steps ? s_fused * 1000.0 / (double)n_fused_steps : 0.0;
+    // With a cluster-resident march the surface kernel of a sub-timestep is 1/n_sub of the fused launch (the
+    // streamed remainder, if any, runs beside it on another stream).
+    if (surf_us) *surf_us = n_fused_steps ? fused_us : stream_surf;
+    if (substep_us) *substep_us = n_fused_steps ? std::max(fused_us, stream_all) : stream_all;
+    if (n_samples) *n_samples = n_fused_steps ? n_fused_steps : (int64_t)n;
     b->ev_used = 0;
+    b->ev_triples.clear();
+    b->ev_fused_pairs.clear();
     return HEAT_OK;
 }
+
+int heat_batch_set_fusion(heat_batch *b, int32_t enabled) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    b->fusion_on = enabled != 0;
+    return HEAT_OK;
+}
+
+int64_t heat_batch_n_fused_surfaces(const heat_batch *b) { return b ? b->n_fused_surfaces : 0; }
 
 }  // extern "C"

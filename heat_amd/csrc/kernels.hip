@@ -55,6 +55,41 @@ __device__ __forceinline__ double boundary_temperature(const SideConst &c, const
 
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
 
+// Neighbour exchange across the whole wavefront as DPP rotates (VALU speed; a ds_bpermute round trip through the
+// LDS crossbar costs ~100 cycles of dependent latency per RK stage). from_prev: lane l receives lane l - 1's
+// value (lane 0 receives lane 63's); from_next: lane l receives lane l + 1's (lane 63 receives lane 0's).
+template <int CTRL>
+__device__ __forceinline__ double dpp_rotate_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the wavefront with DPP (row shifts inside the rows of 16 lanes, then the two row broadcasts): the
+// total arrives in lane 63 and is handed to every lane. A fixed tree: run-to-run deterministic, the same in
+// k_zones and in the cluster-resident march.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3 add the sum of the row before
+    v = dpp_add_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3 add the sum of rows 0-1
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double from_prev_lane(double v) { return dpp_rotate_f64<0x13C>(v); }  // wave_ror:1
+__device__ __forceinline__ double from_next_lane(double v) { return dpp_rotate_f64<0x134>(v); }  // wave_rol:1
+
 // ---------------------------------------------------------------------------
 // Fast path. One wavefront per tile; see layout.hpp for the lane blocking.
 //
@@ -75,8 +110,8 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
                                          double (&acc)[M], const double (&V)[M], const double (&U)[M], double UL,
                                          bool is_first, bool is_last, int jl, double hF, double qF, double hB,
                                          double qB, int lane) {
-    double xl = __shfl(in[M - 1], (lane + kWave - 1) & (kWave - 1), kWave);
-    const double xr = __shfl(in[0], (lane + 1) & (kWave - 1), kWave);
+    double xl = from_prev_lane(in[M - 1]);
+    const double xr = from_next_lane(in[0]);
     // never let another surface's value (possibly NaN) in: the first lane has no left neighbour
     double fprev = is_first ? (hF * in[0] - qF) : UL * (in[0] - xl);
 #pragma unroll
@@ -110,19 +145,51 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
 // CAV = 1: up to two gas cavities between massive nodes; their conductance (Cavity::u_value, cavity.rs:59-69)
 // is evaluated once per sub-timestep from the temperatures the massive chunk starts from, as get_k_q does
 // (discretization.rs:634-639), and frozen over the four RK stages (surface.rs:268-293).
-template <int M, int NM, int PAL, int CAV>
-__global__ void __launch_bounds__(256)
+// FUSED = 1: cluster-resident march (layout.hpp, FusedBlock). One workgroup holds every surface facing its
+// zones; it marches fa.n_sub sub-timesteps of ThermalModel::march (model.rs:369-424) in one launch: the node
+// temperatures never leave the registers, the zone balance (calculate_zones_abc + the analytic update,
+// model.rs:489-597,650-674) is summed from LDS in the same order and with the same arithmetic as k_zones, and
+// only the final temperatures, coefficients and flows are written back.
+// (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1 and CAV = 0: V and U are looked
+// up in the LDS palettes again every sub-timestep instead of being held in registers across the march.)
+template <int M, int NM, int PAL, int CAV, int FUSED>
+__global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, FUSED ? 2 : 1)
 k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                 const double *__restrict__ zone_T, int *__restrict__ flags,
-                unsigned long long *__restrict__ nomass_iters) {
+                unsigned long long *__restrict__ nomass_iters, FusedArgs fa) {
+    static_assert(!FUSED || (PAL && !CAV), "the cluster-resident march exists for palette classes without cavities");
+    constexpr int kMaxW = FUSED ? FUSED : 4;
+    constexpr int kLanes = kMaxW * kWave;
+    // LDS: the palettes of the block's tiles; FUSED adds the per-side (hs, face temperature) pairs the zone
+    // balance is summed from, [2][kLanes] double2, and the zone temperatures (dynamic: > 64 KB for 8 waves).
+    extern __shared__ double s_dyn[];
+    __shared__ double s_pal_static[(PAL && !FUSED) ? kLanes * kPal : 2];
+    double *const s_pal = FUSED ? s_dyn : s_pal_static;
+    // FUSED, after the palettes: (hs * area, face temperature) per side [2][kLanes] double2; zone temperatures,
+    // a0, b0, volume [kFusedMaxZones] each; first slot of every zone [kFusedMaxZones + 1]; the slot lists.
+    double2 *const s_hT = reinterpret_cast<double2 *>(s_dyn + kLanes * kPal);
+    double *const s_zT = s_dyn + kLanes * kPal + 4 * kLanes;
+    double *const s_za0 = s_zT + kFusedMaxZones;
+    double *const s_zb0 = s_za0 + kFusedMaxZones;
+    double *const s_zvol = s_zb0 + kFusedMaxZones;
+    int *const s_zoff = reinterpret_cast<int *>(s_zvol + kFusedMaxZones);
+    unsigned short *const s_slots = reinterpret_cast<unsigned short *>(s_zoff + kFusedMaxZones + 2);
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
-    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
-    const StepWeather w = weather[step];
-    // Persistent waves: each walks the tile list with a grid stride, so the write-back of one tile (a wave
-    // cannot retire before its stores are acknowledged) overlaps the loads of the next.
+    const int wib = threadIdx.x >> 6;
+    int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
+    int n_waves = gridDim.x * (blockDim.x >> 6);
+    FusedBlock blk{0, 0, 0, 0};
+    if constexpr (FUSED) {
+        blk = fa.blocks[blockIdx.x];
+        if (wib >= blk.n_tiles) return;  // (before any barrier: a finished wave does not take part in s_barrier)
+        wave0 = blk.first_tile + wib;
+        n_waves = 1 << 30;
+    }
+    const int n_it = FUSED ? fa.n_sub : 1;
+    const int step0 = FUSED ? 0 : ((step_fixed >= 0) ? step_fixed : *step_ptr);
+    // Streaming (FUSED = 0), persistent waves: each walks the tile list with a grid stride, so the write-back of
+    // one tile (a wave cannot retire before its stores are acknowledged) overlaps the loads of the next.
     for (int wave = wave0; wave < n_tiles; wave += n_waves) {
     const FastTile tile = tiles[wave];
     const int k = tile.k & 0xff;
@@ -146,34 +213,37 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const int sidx = (my_back ? S : 0) + d;
     const SideConst c = sd.sc[sidx];
     const SideDyn dy = sd.dyn[sidx];
+    // (FUSED workgroups hold surfaces of two or more lanes only — the host sees to it — so the "this lane owns
+    // both sides" path of single-lane surfaces is not compiled into them.)
+    int my_lz = 0;
+    double my_area = 0.0;
+    if constexpr (FUSED) {
+        my_lz = fa.side_lzone[sidx];
+        my_area = fa.side_area[sidx];
+    }
 
     // ---- node data: T, V = dt/C, U (coalesced 16-byte loads) ----
     double T[M], V[M], U[M];
+    unsigned int cw[M / 4];  // PAL: the lane's class bytes, four per word
+    (void)cw;
     if constexpr (PAL) {
-        __shared__ double s_pal[4][kWave * kPal];
-        double *sp = s_pal[threadIdx.x >> 6];
+        double *sp = s_pal + wib * (kWave * kPal);
         {   // the palettes of this tile's surfaces: G * kPal contiguous doubles -> LDS
             const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * kPal);
             double2 *sp2 = reinterpret_cast<double2 *>(sp);
             const int n2 = G * (kPal / 2);
             for (int i = lane; i < n2; i += kWave) sp2[i] = gp[i];
         }
-        unsigned char cb[M];
         {
             const unsigned char *pc = na.cls + tile.node_base + (int64_t)ll * M;
             if constexpr (M == 4) {
-                const unsigned int w0 = *reinterpret_cast<const unsigned int *>(pc);
-#pragma unroll
-                for (int j = 0; j < 4; j++) cb[j] = (w0 >> (8 * j)) & 0xff;
+                cw[0] = *reinterpret_cast<const unsigned int *>(pc);
             } else {
 #pragma unroll
                 for (int q = 0; q < M / 8; q++) {
                     const uint2 w0 = reinterpret_cast<const uint2 *>(pc)[q];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        cb[8 * q + j] = (w0.x >> (8 * j)) & 0xff;
-                        cb[8 * q + 4 + j] = (w0.y >> (8 * j)) & 0xff;
-                    }
+                    cw[2 * q] = w0.x;
+                    cw[2 * q + 1] = w0.y;
                 }
             }
         }
@@ -184,11 +254,14 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             T[2 * jp] = t.x; T[2 * jp + 1] = t.y;
         }
         __builtin_amdgcn_wave_barrier();  // LDS writes above are ordered before the reads below (same wave)
-        const double *mp = sp + g * kPal;
+        if constexpr (!FUSED) {
+            const double *mp = sp + g * kPal;
 #pragma unroll
-        for (int j = 0; j < M; j++) {
-            V[j] = mp[cb[j] & (kPalV - 1)];
-            U[j] = mp[kPalV + (cb[j] >> 3)];
+            for (int j = 0; j < M; j++) {
+                const unsigned int cbj = (cw[j >> 2] >> (8 * (j & 3))) & 0xff;
+                V[j] = mp[cbj & (kPalV - 1)];
+                U[j] = mp[kPalV + (cbj >> 3)];
+            }
         }
     } else {
         const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
@@ -203,6 +276,20 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             V[2 * jp] = v.x; V[2 * jp + 1] = v.y;
             U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
         }
+    }
+    if constexpr (FUSED) {
+        const int e_first = fa.zone_eoff[blk.first_zone];
+        if (threadIdx.x <= blk.n_zones) s_zoff[threadIdx.x] = fa.zone_eoff[blk.first_zone + threadIdx.x] - e_first;
+        if (threadIdx.x < blk.n_zones) {
+            const int z = fa.zones[blk.first_zone + threadIdx.x];
+            s_zT[threadIdx.x] = fa.zone_T[z];
+            s_za0[threadIdx.x] = fa.a0[z];
+            s_zb0[threadIdx.x] = fa.b0[z];
+            s_zvol[threadIdx.x] = fa.vol[z];
+        }
+        const int n_e = fa.zone_eoff[blk.first_zone + blk.n_zones] - e_first;
+        for (int e = threadIdx.x; e < n_e; e += blk.n_tiles * kWave) s_slots[e] = fa.slots[e_first + e];
+        __syncthreads();  // the block's zone data are in LDS
     }
 
     const int first_lane = g * k;
@@ -219,15 +306,60 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         return r;
     };
 
+    int4 cavref = make_int4(-1, -1, -1, -1);
+    if constexpr (CAV) cavref = reinterpret_cast<const int4 *>(na.cavref)[d];
+    SideConst cb2 = c;
+    SideDyn db2 = dy;
+    if constexpr (!FUSED) {
+        if (k == 1) {  // single-lane surfaces: this lane is also the last one
+            cb2 = sd.sc[S + d];
+            db2 = sd.dyn[S + d];
+        }
+    }
+
+    int bad_all = 0;
+    unsigned int nm_passes = 0;
+    double o_hs = 0.0, o_flow = 0.0, o2_hs = 0.0, o2_flow = 0.0;  // outputs of the last sub-timestep
+    double aux[M];
+    StepWeather w_next = weather[step0];
+
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < n_it; it++) {  // sub-timesteps (one, unless FUSED)
+    const StepWeather w = w_next;
+    if constexpr (FUSED) w_next = weather[min(it + 1, n_it - 1)];  // fetched a whole sub-timestep ahead of its use
+    if constexpr (FUSED) {  // V = dt/C and U of this lane's nodes, from the tile's palettes in LDS
+        const double *mp = s_pal + wib * (kWave * kPal) + g * kPal;
+        // (opaque to the optimiser: otherwise the 2 M palette addresses are hoisted out of the sub-timestep loop
+        // and held in registers for the whole march)
+#pragma unroll
+        for (int q = 0; q < M / 4; q++) asm volatile("" : "+v"(cw[q]));
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            const unsigned int cbj = (cw[j >> 2] >> (8 * (j & 3))) & 0xff;
+            V[j] = mp[cbj & (kPalV - 1)];
+            U[j] = mp[kPalV + (cbj >> 3)];
+        }
+    }
+    // get_boundary_temperature, model.rs:79-96 (FUSED: zone temperatures live in LDS)
+    auto btemp = [&](const SideConst &cc, int lz) -> double {
+        const int kind = cc.kind_n & 3;
+        if (kind == KIND_SPACE) {
+            if constexpr (FUSED) return s_zT[lz];
+            else return zone_T[cc.zone];
+        }
+        if (kind == KIND_AMBIENT) return cc.ambient;
+        return w.t_out;
+    };
+
     int bad = 0;
     // The part of calc_border_conditions (surface.rs:596-717) that does not change inside a sub-timestep:
     // boundary temperature, radiant temperature, forced convection term, and whether the side reads the
     // FRONT surface temperature (back/Ambient takes t_front and the front temperature, surface.rs:672-686).
     // Kept in plain scalars (a struct here ends up in scratch memory).
-    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, double &air_t, double &rad_t,
-                       double &forced, double &fix, bool &use_front_T) {
+    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, int lz, double &air_t,
+                       double &rad_t, double &forced, double &fix, bool &use_front_T) {
         const int kind = cc.kind_n & 3;
-        air_t = boundary_temperature(cc, w, zone_T);
+        air_t = btemp(cc, lz);
         rad_t = air_t;
         use_front_T = false;
         forced = 0.0;
@@ -237,7 +369,9 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             rad_t = dd.rad_t;                                            // surface.rs:647,692
         } else if (back && kind == KIND_AMBIENT) {
             const SideConst fc = sd.sc[rec - S];
-            rad_t = boundary_temperature(fc, w, zone_T);
+            int flz = 0;
+            if constexpr (FUSED) flz = fa.side_lzone[rec - S];
+            rad_t = btemp(fc, flz);
             use_front_T = true;
         }
         fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
@@ -254,12 +388,11 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const double Tn = shfl_f64(pick_last(T), last_lane);
 
     // Conductance towards the previous lane's last node.
-    double UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
+    double UL = from_prev_lane(U[M - 1]);
     if (is_first) UL = 0.0;
-    unsigned int nm_passes = 0;
     // Last node of the previous lane (wave-wide exchange: must not sit inside a divergent branch).
     double T_prev_last = 0.0;
-    if constexpr (NM) T_prev_last = shfl_f64(T[M - 1], (lane + kWave - 1) & (kWave - 1));
+    if constexpr (NM) T_prev_last = from_prev_lane(T[M - 1]);
 
     // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769).
     double hF = 0.0, qF = 0.0, hB = 0.0, qB = 0.0;
@@ -329,7 +462,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 
     double my_air, my_rad, my_forced, my_fix;
     bool my_useF;
-    prepare(c, dy, my_back, sidx, my_air, my_rad, my_forced, my_fix, my_useF);
+    prepare(c, dy, my_back, sidx, my_lz, my_air, my_rad, my_forced, my_fix, my_useF);
     if (is_first || is_last) {
         double h_, q_;
         add_face(c, dy, my_back, my_air, my_rad, my_forced, my_fix, my_useF, h_, q_);
@@ -340,22 +473,21 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     }
     double b_air = 0.0, b_forced = 0.0, b_fix = 0.0, b_cos = 0.0;
     bool b_useF = false;
-    if (k == 1) {  // single-lane surfaces: this lane is also the last one
-        const SideConst cb2 = sd.sc[S + d];
-        const SideDyn db2 = sd.dyn[S + d];
-        double b_rad;
-        prepare(cb2, db2, true, S + d, b_air, b_rad, b_forced, b_fix, b_useF);
-        b_cos = cb2.cos_eff;
-        add_face(cb2, db2, true, b_air, b_rad, b_forced, b_fix, b_useF, hB, qB);
+    if constexpr (!FUSED) {
+        if (k == 1) {  // single-lane surfaces: this lane is also the last one
+            double b_rad;
+            prepare(cb2, db2, true, S + d, 0, b_air, b_rad, b_forced, b_fix, b_useF);
+            b_cos = cb2.cos_eff;
+            add_face(cb2, db2, true, b_air, b_rad, b_forced, b_fix, b_useF, hB, qB);
+        }
     }
 
     if constexpr (CAV) {
-        const double T_next_first = shfl_f64(T[0], (lane + 1) & (kWave - 1));
-        const int4 ref = reinterpret_cast<const int4 *>(na.cavref)[d];
+        const double T_next_first = from_next_lane(T[0]);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const int node = r ? ref.z : ref.x;
-            const int cidx = r ? ref.w : ref.y;
+            const int node = r ? cavref.z : cavref.x;
+            const int cidx = r ? cavref.w : cavref.y;
             const int jc = node - seg * M;
             if (active && cidx >= 0 && jc >= 0 && jc < M) {
                 double ta = T[0], tb = T_next_first;
@@ -369,12 +501,12 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 for (int j = 0; j < M; j++) U[j] = (j == jc) ? u : U[j];
             }
         }
-        UL = shfl_f64(U[M - 1], (lane + kWave - 1) & (kWave - 1));
+        UL = from_prev_lane(U[M - 1]);
         if (is_first) UL = 0.0;
     }
 
     // ---- RK4 (surface.rs:228-308) ----
-    double acc[M], aux[M];
+    double acc[M];
     if (full) {
         rk_stage<M, true, 0>(T, T, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
         rk_stage<M, true, 1>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
@@ -387,11 +519,13 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         rk_stage<M, false, 3>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     }
 
-    // ---- write back node temperatures (model.rs:145-147) ----
-    if (active) {
-        double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
+    // ---- write back node temperatures (model.rs:145-147); FUSED: after the last sub-timestep only ----
+    if constexpr (!FUSED) {
+        if (active) {
+            double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
 #pragma unroll
-        for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(aux[2 * jp], aux[2 * jp + 1]);
+            for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(aux[2 * jp], aux[2 * jp + 1]);
+        }
     }
 
     // ---- convection coefficients with the NEW temperatures + heat flows (model.rs:150-169) ----
@@ -402,25 +536,74 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         const double surf_t = (my_back && !my_useF) ? Tnn : T0n;
         const double hs = conv(my_air, my_forced, c.cos_eff, my_fix, surf_t);
         const double face_t = my_back ? Tln : aux[0];
-        if (active && (is_first || is_last)) {
-            SideOut o;
-            o.hs = hs;
-            o.flow = (face_t - my_air) * hs;
-            sd.out[sidx] = o;
+        o_hs = hs;
+        o_flow = (face_t - my_air) * hs;
+        if constexpr (FUSED) {
+            if (active && (is_first || is_last) && (c.kind_n & 3) == KIND_SPACE)
+                s_hT[(my_back ? kLanes : 0) + wib * kWave + lane] = make_double2(hs * my_area, face_t);
         }
     }
-    if (k == 1) {
+    if (!FUSED && k == 1) {
         const double hs = conv(b_air, b_forced, b_cos, b_fix, b_useF ? T0n : Tnn);
-        if (active) {
-            SideOut o;
-            o.hs = hs;
-            o.flow = (Tln - b_air) * hs;
-            sd.out[S + d] = o;
-        }
+        o2_hs = hs;
+        o2_flow = (Tln - b_air) * hs;
     } else if (!(is_first || is_last)) {
         bad = 0;
     }
-    if (active && bad) atomicOr(flags, bad);
+    bad_all |= bad;
+
+    if constexpr (FUSED) {
+        // ---- zones of the block: calculate_zones_abc + estimate_zones_future_temperatures, as k_zones does ----
+        if (!(fa.pad & 4)) __syncthreads();
+#pragma clang loop unroll(disable)
+        for (int j = wib; j < blk.n_zones && !(fa.pad & 2); j += blk.n_tiles) {
+            const int e0 = s_zoff[j], e1 = s_zoff[j + 1];
+            double a = 0.0, b = 0.0;
+            for (int e = e0 + lane; e < e1; e += kWave) {  // model.rs:562-585
+                const double2 ht = s_hT[s_slots[e]];
+                a += ht.x * ht.y;
+                b += ht.x;
+            }
+            a = wave_sum_f64(a);
+            b = wave_sum_f64(b);
+            if (lane == 0 && !(fa.pad & 1)) {
+                a += s_za0[j];
+                b += s_zb0[j];
+                const double tc = s_zT[j];
+                const double cz = zone_mcp(s_zvol[j], tc);  // model.rs:549-552
+                double ft = tc;
+                if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * fa.dt / cz);  // model.rs:662-666
+                if (ft != ft) bad_all |= FLAG_NAN_ZONE;                                // model.rs:417-420
+                s_zT[j] = ft;
+            }
+        }
+        if (!(fa.pad & 4)) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < M; j++) T[j] = aux[j];
+    }
+    }  // sub-timesteps
+
+    if constexpr (FUSED) {
+        if (active) {
+            double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
+#pragma unroll
+            for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(aux[2 * jp], aux[2 * jp + 1]);
+        }
+        if (threadIdx.x < blk.n_zones) fa.zone_T[fa.zones[blk.first_zone + threadIdx.x]] = s_zT[threadIdx.x];
+    }
+    if (active && (is_first || is_last)) {
+        SideOut o;
+        o.hs = o_hs;
+        o.flow = o_flow;
+        sd.out[sidx] = o;
+    }
+    if (!FUSED && k == 1 && active) {
+        SideOut o;
+        o.hs = o2_hs;
+        o.flow = o2_flow;
+        sd.out[S + d] = o;
+    }
+    if (active && bad_all) atomicOr(flags, bad_all);
     if constexpr (NM) {
         // passes of the no-mass loop, summed per tile (one owner per slot: no atomics on a shared word)
         unsigned int tot = nm_passes;
@@ -807,6 +990,7 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
 // Zones: one wavefront per zone.
 //   mode 0: every zone, full update (single GPU).
 //   mode 1: every zone, write the partial (a, b) into partial[2][n_zones] only.
+//   mode 3: as mode 0, but only the zones in zlist[n_list] (the others are owned by fused workgroups).
 //   mode 2: sharded: only the zones in zlist[n_list] (those this rank's surfaces touch); a zone no other rank
 //           touches (slot_of[z] < 0) is updated here and now, a shared one writes its partial (a, b) into the
 //           compact partial[2][n_shared] at its slot for the exchange.
@@ -819,9 +1003,9 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
         int n_list, const int32_t *__restrict__ slot_of, int n_shared) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && mode == 0) *step_ptr += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (mode == 0 || mode == 3)) *step_ptr += 1;
     int z = wv;
-    if (mode == 2) {
+    if (mode == 2 || mode == 3) {
         if (wv >= n_list) return;
         z = zlist[wv];
     }
@@ -835,11 +1019,8 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
         a += ha * T[en.t_index];
         b += ha;
     }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {  // fixed tree: run-to-run deterministic
-        a += __shfl_down(a, o, kWave);
-        b += __shfl_down(b, o, kWave);
-    }
+    a = wave_sum_f64(a);  // fixed tree: run-to-run deterministic
+    b = wave_sum_f64(b);
     if (lane != 0) return;
     if (mode == 1) {
         partial[z] = a;
@@ -1043,9 +1224,10 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     // (M = 4 tiles are too small for it: 1 M x 20 nodes ran 172 us persistent vs 155 us one wave per tile.)
     const bool persistent = tune > 0 && grid_share > 0.999 && M >= 8;
     const dim3 grid(persistent ? std::min(full_grid, n_cu * blocks_per_cu) : full_grid), block(256);
-#define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                       \
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
-                       step_ptr, step_fixed, zone_T, flags, nomass_iters)
+    const FusedArgs no_fa{};
+#define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                          \
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC, 0>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
+                       step_ptr, step_fixed, zone_T, flags, nomass_iters, no_fa)
 #define HEAT_LAUNCH_M(MM)                                     \
     switch ((nm ? 3 : 0) + (cav ? 2 : (pal ? 1 : 0))) {       \
     case 0: HEAT_LAUNCH_FAST(MM, 0, 0, 0); break;             \
@@ -1058,6 +1240,47 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     if (M == 4) { HEAT_LAUNCH_M(4) } else if (M == 8) { HEAT_LAUNCH_M(8) } else { HEAT_LAUNCH_M(16) }
 #undef HEAT_LAUNCH_M
 #undef HEAT_LAUNCH_FAST
+}
+
+// Cluster-resident march of one class: one workgroup of `max_waves` (4 or 8) wavefronts per FusedBlock, fa.n_sub
+// sub-timesteps in one launch. Palette classes without cavities only.
+size_t fused_lds_bytes(int max_waves) {
+    return (size_t)max_waves * kWave * (kPal * sizeof(double) + 2 * sizeof(double2)) +
+           4 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
+}
+
+template <int MM, int NN, int FW>
+static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+                                   const SideArrays &sa, const StepWeather *weather, int *flags,
+                                   unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
+    const size_t lds = fused_lds_bytes(FW);
+    static bool attr_set = false;  // (per instantiation) dynamic LDS above the 64 KB default needs the attribute
+    if (!attr_set) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, 0, FW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, 0, FW>), dim3(n_blocks), dim3(kWave * FW), lds, st, tiles, n_tiles, na,
+                       sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
+    return hipSuccess;
+}
+
+hipError_t launch_surfaces_fused(int M, int nm, int max_waves, int n_blocks, const FastTile *tiles, int n_tiles,
+                                 const NodeArrays &na, const SideArrays &sa, const StepWeather *weather, int *flags,
+                                 unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
+    if (n_blocks <= 0) return hipSuccess;
+#define HEAT_FUSED(MM, NN, FW) launch_fused_one<MM, NN, FW>(n_blocks, tiles, n_tiles, na, sa, weather, flags, nomass_iters, fa, st)
+#define HEAT_FUSED_M(MM)                                          \
+    (max_waves <= 4 ? (nm ? HEAT_FUSED(MM, 1, 4) : HEAT_FUSED(MM, 0, 4)) \
+                    : (nm ? HEAT_FUSED(MM, 1, 8) : HEAT_FUSED(MM, 0, 8)))
+    if (M == 4) return HEAT_FUSED_M(4);
+    if (M == 8) return HEAT_FUSED_M(8);
+    return HEAT_FUSED_M(16);
+#undef HEAT_FUSED_M
+#undef HEAT_FUSED
 }
 
 void launch_surfaces_general(const GeneralTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base,
@@ -1086,7 +1309,7 @@ void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const doubl
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
                   const int32_t *slot_of, int n_shared, hipStream_t st) {
-    const int n_waves = (mode == 2) ? n_list : n_zones;
+    const int n_waves = (mode == 2 || mode == 3) ? n_list : n_zones;
     if (mode == 2 && n_waves <= 0) return;
     const int nb = n_waves > 0 ? blocks_for_waves(n_waves) : 1;
     hipLaunchKernelGGL(k_zones, dim3(nb), dim3(256), 0, st, zone_off, entries, T, hs, a0, b0, zone_vol, zone_T,

@@ -117,6 +117,35 @@ struct StepWeather {
     double sin_wd, cos_wd;
 };
 
+// Cluster-resident march ("fused"): one workgroup owns whole zone-connected clusters — every surface
+// that faces one of its zones — so the zone balance of a sub-timestep is done in LDS and the node temperatures
+// stay in registers over all sub-timesteps of a march.
+constexpr int kFusedMaxWaves = 8;    // tiles (wavefronts) per workgroup
+constexpr int kFusedMaxZones = 32;   // zones per workgroup
+constexpr int kFusedMaxEntries = 1024;  // zone-facing sides per workgroup
+struct FusedBlock {
+    int32_t first_tile;  // into the class's tile list; the block's tiles are contiguous
+    int32_t n_tiles;     // <= kFusedMaxWaves
+    int32_t first_zone;  // into FusedArgs::zones / zone_eoff
+    int32_t n_zones;     // <= kFusedMaxZones
+};
+// A contribution to a zone's heat balance (model.rs:562-585) is the LDS slot of the side that makes it:
+//   slot = side * (64 * W) + wave_in_block * 64 + lane of the side's owner   (W = 4 or 8, the block's width group)
+// listed per zone in the reference's order.
+struct FusedArgs {
+    const FusedBlock *blocks;
+    const int32_t *zones;       // global zone number of the block-local zone (first_zone + j)
+    const int32_t *zone_eoff;   // slots of that zone: [zone_eoff[first_zone + j], zone_eoff[first_zone + j + 1])
+    const uint16_t *slots;
+    const double *side_area;    // [2 * S]: area of the surface, per side record
+    const int16_t *side_lzone;  // [2 * S]: block-local zone of a side, -1 unless the side faces a Space
+    const double *a0, *b0, *vol;
+    double *zone_T;
+    double dt;
+    int32_t n_sub;              // sub-timesteps marched by one launch
+    int32_t pad;
+};
+
 struct ZoneEntry {
     uint32_t t_index;   // index into NodeArrays::T of the face node
     uint32_t hs_index;  // side record index (side * S + d) into SideArrays::out

@@ -145,7 +145,7 @@ typedef struct heat_batch_options {
     int32_t n_ranks;
     int32_t rank;
     int32_t no_palette;      /* 1: keep dt/mass and U as per-node arrays even where a palette would do */
-    int32_t reserved;
+    int32_t no_fusion;       /* 1: never plan the cluster-resident march (see heat_batch_set_fusion) */
 } heat_batch_options;
 
 /* ≙ ThermalModel::new + allocate_memory: validates, packs and uploads the constants. */
@@ -216,6 +216,19 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
 int heat_comm_unique_id(uint8_t id[HEAT_COMM_ID_BYTES]);
 int heat_batch_comm_init(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES]);
 int32_t heat_batch_n_shared_zones(const heat_batch *b);
+
+/*
+ * Cluster-resident march (on by default). ThermalModel::march runs its dt_subdivisions sub-timesteps back to back
+ * and nothing outside reads the state in between (model.rs:369-424), and surfaces exchange heat only through the
+ * zones they face (model.rs:556-590). So the batch is cut into zone-connected clusters; a cluster whose surfaces
+ * are all palette-form fast-path walls without gas cavities and that fits one workgroup (8 wavefronts, 32 zones)
+ * is marched for ALL n_sub sub-timesteps of a heat_batch_march[_resident] call by one workgroup: node temperatures
+ * stay in registers, the zone balance is summed in LDS in the reference's order, and only the final temperatures,
+ * coefficients and flows are written. Everything else is streamed one sub-timestep per launch beside it. Results are
+ * the same as the streamed march's to the last bit of the zone sums' order (tested at 1e-9 against the oracle).
+ * heat_batch_set_fusion(b, 0) streams everything (used to measure the per-sub-timestep kernel on its own). */
+int heat_batch_set_fusion(heat_batch *b, int32_t enabled);
+int64_t heat_batch_n_fused_surfaces(const heat_batch *b);
 
 /* Introspection (tests, bench). */
 int64_t heat_batch_n_surfaces(const heat_batch *b);
