@@ -7,6 +7,13 @@ north_star headline of BASELINE.json: 1 000 000 all-massive surfaces x 32 nodes 
 (weak scaling: every rank holds its own million), RK4 + convection / long-wave / solar boundary
 updates, zones of 100 surfaces. State is resident in HBM when the timed region starts.
 
+The K timed steps are issued as march calls of --substeps-per-march sub-timesteps each (default 20:
+a 15-minute model timestep at dt = 45 s), as ThermalModel::march runs its dt_subdivisions
+sub-timesteps per call. Inside one call the library keeps zone-connected clusters of surfaces
+resident on the chip (cluster-resident march, include/heat_amd.h); --no-fusion streams every
+sub-timestep through HBM instead, and a second, shorter leg always measures that streamed kernel
+(`roofline_streaming`) so that the per-sub-timestep HBM roofline stays on record.
+
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -85,10 +92,11 @@ def cpu_baseline(n, dt, seed, target_seconds=12.0):
     return out
 
 
-def pmc_traffic(surfaces, nodes):
+def pmc_traffic(surfaces, nodes, mode="streamed", substeps=1):
     """HBM bytes per launch of the surface kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; bench.py cannot run the profiler on itself). None when no
-    committed measurement matches this workload."""
+    committed measurement matches this workload and kernel (mode: "streamed" = one sub-timestep per launch,
+    "fused" = `substeps` sub-timesteps per launch)."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -97,9 +105,45 @@ def pmc_traffic(surfaces, nodes):
                 j = json.load(open(os.path.join(pdir, f)))
             except Exception:
                 continue
-            if j.get("workload", {}).get("surfaces") == surfaces and j.get("workload", {}).get("nodes") == nodes:
-                best = (j["traffic_bytes_per_launch"], "profiles/" + f)
+            wl = j.get("workload", {})
+            if wl.get("surfaces") != surfaces or wl.get("nodes") != nodes or wl.get("mode", "streamed") != mode:
+                continue
+            if mode == "fused" and wl.get("substeps_per_launch") != substeps:
+                continue
+            best = (j["traffic_bytes_per_launch"], "profiles/" + f)
     return best if best else (None, None)
+
+
+def march_in_calls(march, weather, per_call):
+    """K sub-timesteps as march calls of `per_call` sub-timesteps (ThermalModel::march = one call)."""
+    for i in range(0, len(weather), per_call):
+        march(weather[i:i + per_call])
+
+
+def streaming_leg(md, state, args, dt, steps=60, warmup=10):
+    """The per-sub-timestep kernel on its own: a batch planned without the cluster-resident march
+    (16 nodes per lane, persistent waves), HIP events around every launch."""
+    from heat_amd import HeatBatch, modeldict as mdl
+    with HeatBatch(md, nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=True) as b:
+        b.upload_state(state)
+        b.march_resident(mdl.weather_series(warmup, dt))
+        b.synchronize()
+        b.set_timing(True)
+        t0 = time.perf_counter()
+        b.march_resident(mdl.weather_series(steps, dt, t0=dt * warmup))
+        b.synchronize()
+        el = time.perf_counter() - t0
+        surf_us, substep_us, n = b.get_timing()
+        ab = b.algorithmic_bytes
+        counts = b.class_counts()
+    achieved = ab / (surf_us * 1e-6) / 1e9
+    traffic, src = pmc_traffic(args.surfaces, args.nodes, "streamed")
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "kernel": "k_surfaces_fast<M,...,0> (iterate_surfaces, one sub-timestep per launch, state streamed through HBM)",
+            "algorithmic_bytes_per_launch": ab, "kernel_us": surf_us, "substep_us": substep_us, "samples": n,
+            "node_updates_per_sec": int(md["node_offset"][-1]) * steps / el,
+            "kernel_classes[M4,M8,M16,small,general]": counts}
 
 
 def main():
@@ -113,6 +157,11 @@ def main():
     ap.add_argument("--nodes-per-lane", type=int, default=0)
     ap.add_argument("--no-palette", action="store_true", help="keep dt/mass and U as per-node arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--substeps-per-march", type=int, default=20,
+                    help="sub-timesteps per march call (ThermalModel::march runs dt_subdivisions of them per call)")
+    ap.add_argument("--no-fusion", action="store_true",
+                    help="stream every sub-timestep through HBM (no cluster-resident march)")
+    ap.add_argument("--no-streaming-leg", action="store_true", help="skip the second leg that measures the streamed kernel")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
@@ -158,7 +207,7 @@ def main():
         if args.force_shared_zones > 0:
             forced = np.unique(np.linspace(0, args.zones_per_gpu * world - 1, args.force_shared_zones).astype(np.int32))
         sm = ShardedMarch(md, rank, world, device_index=local_rank, collective=args.collective, force_shared=forced,
-                          nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette)
+                          nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=args.no_fusion)
         batch = sm.batch
         batch.upload_state(state)
 
@@ -170,7 +219,7 @@ def main():
         run = sm.march_resident
     else:
         batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True,
-                          no_palette=args.no_palette)
+                          no_palette=args.no_palette, no_fusion=args.no_fusion)
         batch.upload_state(state)
 
         def barrier():
@@ -178,12 +227,13 @@ def main():
 
         run = batch.march_resident
 
+    P = max(1, args.substeps_per_march)
     if W > 0:
-        run(weather_w[:W])
+        march_in_calls(run, weather_w[:W], P)
     barrier()
     batch.set_timing(not args.no_timing)
     t0 = time.perf_counter()
-    run(weather_k)
+    march_in_calls(run, weather_k, P)
     barrier()
     elapsed = time.perf_counter() - t0
     surf_us, substep_us, n_samples = batch.get_timing()
@@ -198,6 +248,8 @@ def main():
 
     algorithmic_bytes = batch.algorithmic_bytes
     counts = batch.class_counts()
+    n_fused = batch.n_fused_surfaces if not args.no_fusion else 0
+    fused = n_fused > 0
     total_nodes = n_nodes_local * world
     value = total_nodes * K / elapsed
     result = {
@@ -219,8 +271,9 @@ def main():
                         "long-wave + solar boundaries, %d zones per GPU, dt = %g s; one step = one sub-timestep "
                         "(iterate_surfaces + zone update)" % (args.surfaces, args.nodes, args.zones_per_gpu, dt),
             "surfaces_per_gpu": args.surfaces, "nodes_per_surface": args.nodes,
-            "zones_per_gpu": args.zones_per_gpu, "dt_s": dt,
+            "zones_per_gpu": args.zones_per_gpu, "dt_s": dt, "substeps_per_march": P,
             "kernel_classes[M4,M8,M16,small,general]": counts,
+            "surfaces_in_cluster_resident_march": n_fused,
             "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep RCCL all-gather of the partial "
                            "sums of %d shared zones (%s)" % (
                                world, sm.n_shared_zones,
@@ -229,15 +282,28 @@ def main():
         },
     }
     if n_samples > 0:
+        # algorithmic bytes of a launch = SURVEY.md §8(d)'s 32 n + 152 bytes per surface and sub-timestep x the
+        # sub-timesteps the launch marches (1 streamed; P cluster-resident)
+        per_launch = P if fused else 1
         achieved = algorithmic_bytes / (surf_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic(args.surfaces, args.nodes)
+        traffic, traffic_src = pmc_traffic(args.surfaces, args.nodes, "fused" if fused else "streamed", per_launch)
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "k_surfaces_fast (iterate_surfaces: RK4 stencil + boundary updates)",
-            "algorithmic_bytes_per_launch": algorithmic_bytes,
-            "kernel_us": surf_us, "substep_us": substep_us, "samples": n_samples,
+            "kernel": ("k_surfaces_fast<M,...,FUSED> (cluster-resident march: %d sub-timesteps of iterate_surfaces + zone "
+                       "update per launch, node temperatures in registers; the streamed kernel's own line is "
+                       "roofline_streaming)" % P) if fused else
+                      "k_surfaces_fast (iterate_surfaces: RK4 stencil + boundary updates, one sub-timestep per launch)",
+            "sub_timesteps_per_launch": per_launch,
+            "algorithmic_bytes_per_launch": algorithmic_bytes * per_launch,
+            "kernel_us": surf_us * per_launch, "kernel_us_per_sub_timestep": surf_us, "substep_us": substep_us,
+            "samples": n_samples,
+            "note": ("frac > 1 is possible: the launch re-uses the state on chip instead of streaming it per "
+                     "sub-timestep, so its HBM traffic is far below the algorithmic (streaming) byte count") if fused else None,
         }
+    if rank == 0 and world == 1 and fused and not args.no_streaming_leg:
+        batch.close()
+        result["roofline_streaming"] = streaming_leg(md, state, args, dt)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.nodes, dt, seed)
     if sharded:

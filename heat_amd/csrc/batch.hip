@@ -162,6 +162,15 @@ struct heat_batch {
     DevBuf<uint16_t> d_fslots;
     DevBuf<double> d_side_area;
     DevBuf<int16_t> d_side_lzone;
+    // the plan as made at create time (heat_batch_set_shared_zones derives the current one from it: a workgroup
+    // that owns a zone shared with another rank is demoted — its tiles and zones are streamed, so that the zone
+    // exchange can happen every sub-timestep)
+    std::vector<FastTile> h_tiles0[kNumFast];
+    std::vector<FusedBlock> h_fblocks0[kNumFast][2];
+    int n_stream_tiles0[kNumFast] = {};
+    std::vector<int32_t> h_fzones;      // global zone of fused-zone index i (FusedBlock::first_zone + j)
+    DevBuf<int32_t> d_zlist_stream;     // sharded: touched zones that no fused workgroup owns (shared ones first)
+    int n_touched_stream = 0;
     std::vector<int32_t> h_zone_block;  // zone -> fused workgroup (global number) or -1
     DevBuf<int32_t> d_stream_zones;     // zones whose balance is done by k_zones (not owned by a fused workgroup)
     int n_stream_zones = 0;
@@ -895,8 +904,14 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     }
     for (int c = 0; c < kNumFast; c++) {
         if (b->h_fblocks[c][0].empty() && b->h_fblocks[c][1].empty()) b->n_stream_tiles[c] = (int)fast_tiles[c].size();
-        for (int g2 = 0; g2 < 2; g2++) HIP_TRY(b->d_fblocks[c][g2].upload(b->h_fblocks[c][g2]));
+        for (int g2 = 0; g2 < 2; g2++) {
+            HIP_TRY(b->d_fblocks[c][g2].upload(b->h_fblocks[c][g2]));
+            b->h_fblocks0[c][g2] = b->h_fblocks[c][g2];
+        }
+        b->h_tiles0[c] = fast_tiles[c];
+        b->n_stream_tiles0[c] = b->n_stream_tiles[c];
     }
+    b->h_fzones = fz;
     HIP_TRY(b->d_fzones.upload(fz));
     HIP_TRY(b->d_fzone_eoff.upload(fz_eoff));
     for (int64_t dd = 0; dd < S; dd++) side_area[dd] = side_area[S + dd] = d->area[orig_of[dd]];
@@ -1081,6 +1096,7 @@ void enqueue_zones(heat_batch *b, int mode) {
     const int32_t *zl = b->d_zlist.p;
     int nl = b->n_touched;
     if (mode == 3) { zl = b->d_stream_zones.p; nl = b->n_stream_zones; }
+    if (mode == 4) { zl = b->d_zlist_stream.p; nl = b->n_touched_stream; mode = 2; }  // sharded, beside a fused march
     launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_side_out.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
                  b->d_flags.p, mode, zl, nl, b->d_slot_of.p, b->n_shared, b->stream);
@@ -1368,6 +1384,62 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
     if (b->comm) HIP_TRY(b->d_gathered.zeros((size_t)b->n_ranks * 2 * std::max(n_shared, 1)));
     if (b->partial_ptr == b->d_partial.p && (size_t)2 * n_shared > b->d_partial.n)
         return fail(HEAT_E_SIZE, "partials buffer too small");
+
+    // ---- cluster-resident march: demote the workgroups that own a shared zone (from the create-time plan) ----
+    // A demoted workgroup's tiles move, as descriptors, behind the streamed tiles of their class; the remaining
+    // workgroups keep their slot lists (those are relative to the block's first tile).
+    b->any_fused = false;
+    int64_t n_fused_now = 0;
+    std::vector<uint8_t> zone_fused(b->n_zones, 0);
+    for (int c = 0; c < kNumFast; c++) {
+        const std::vector<FastTile> &t0 = b->h_tiles0[c];
+        if (b->h_fblocks0[c][0].empty() && b->h_fblocks0[c][1].empty()) continue;
+        std::vector<FastTile> t(t0.begin(), t0.begin() + b->n_stream_tiles0[c]);
+        std::vector<FusedBlock> keep[2];
+        for (int pass = 0; pass < 2; pass++)          // pass 0: demoted blocks' tiles, pass 1: kept blocks' tiles
+            for (int g2 = 0; g2 < 2; g2++)
+                for (const FusedBlock &fb : b->h_fblocks0[c][g2]) {
+                    bool shared = false;
+                    for (int j = 0; j < fb.n_zones; j++) shared = shared || slot[b->h_fzones[fb.first_zone + j]] >= 0;
+                    if ((pass == 0) != shared) continue;
+                    FusedBlock nb = fb;
+                    nb.first_tile = (int32_t)t.size();
+                    t.insert(t.end(), t0.begin() + fb.first_tile, t0.begin() + fb.first_tile + fb.n_tiles);
+                    if (pass == 1) {
+                        keep[g2].push_back(nb);
+                        for (int j = 0; j < fb.n_zones; j++) zone_fused[b->h_fzones[fb.first_zone + j]] = 1;
+                    }
+                }
+        int n_kept_tiles = 0;
+        for (int g2 = 0; g2 < 2; g2++) {
+            for (const FusedBlock &fb : keep[g2]) {
+                n_kept_tiles += fb.n_tiles;
+                for (int q = 0; q < fb.n_tiles; q++) n_fused_now += t[fb.first_tile + q].G;
+            }
+            b->h_fblocks[c][g2] = keep[g2];
+            HIP_TRY(b->d_fblocks[c][g2].upload(keep[g2]));
+            b->any_fused = b->any_fused || !keep[g2].empty();
+        }
+        b->n_stream_tiles[c] = (int)t.size() - n_kept_tiles;
+        HIP_TRY(b->d_fast_tiles[c].upload(t));
+    }
+    {
+        std::vector<int32_t> szl, tz;
+        for (int64_t z = 0; z < b->n_zones; z++) {
+            b->h_zone_block[z] = zone_fused[z] ? 0 : -1;
+            if (!zone_fused[z]) szl.push_back((int32_t)z);
+        }
+        b->n_stream_zones = (int)szl.size();
+        HIP_TRY(b->d_stream_zones.upload(szl));
+        for (int32_t z : zl) if (!zone_fused[z]) tz.push_back(z);
+        b->n_touched_stream = (int)tz.size();
+        HIP_TRY(b->d_zlist_stream.upload(tz));
+    }
+    b->n_fused_surfaces = n_fused_now;
+    if (b->graph_exec) {  // the captured sub-timestep graph holds the old tile counts
+        (void)hipGraphExecDestroy(b->graph_exec);
+        b->graph_exec = nullptr;
+    }
     return HEAT_OK;
 }
 
@@ -1441,6 +1513,28 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         if (!r) return fail(HEAT_E_COMM, "RCCL is not loaded");
         double *saved_partial = b->partial_ptr;
         b->partial_ptr = b->d_partial.p;
+        // The clusters that own no shared zone march beside the exchange loop, in one launch per class on a side
+        // stream: only the few surfaces around the shared zones go through kernel -> all-gather -> kernel every
+        // sub-timestep, and that chain is shorter than the fused march it runs next to.
+        const bool fused = b->any_fused && b->fusion_on && n_sub > 0 && b->side[2] != nullptr;
+        if (fused) {
+            hipStream_t fs = b->side[2];
+            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+            HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
+            hipEvent_t f0 = nullptr, f1 = nullptr;
+            if (b->timing) {
+                f0 = next_event(b); f1 = next_event(b);
+                if (!f0 || !f1) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
+                HIP_TRY(hipEventRecord(f0, fs));
+            }
+            rc = enqueue_fused(b, n_sub, fs);
+            if (rc) return rc;
+            if (b->timing) {
+                HIP_TRY(hipEventRecord(f1, fs));
+                b->ev_fused_pairs.push_back({f0, f1, n_sub});
+            }
+            HIP_TRY(hipEventRecord(b->ev_fused, fs));
+        }
         for (int i = 0; i < n_sub; i++) {
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             if (b->timing) {
@@ -1448,9 +1542,9 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
                 if (!e0 || !e1 || !e2) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
                 HIP_TRY(hipEventRecord(e0, b->stream));
             }
-            enqueue_surfaces(b, i);
+            enqueue_surfaces(b, i, fused);
             if (b->timing) HIP_TRY(hipEventRecord(e1, b->stream));
-            enqueue_zones(b, 2);
+            enqueue_zones(b, fused ? 4 : 2);
             if (b->n_shared > 0) {
                 RCCL_TRY(r, r->AllGather(b->d_partial.p, b->d_gathered.p, (size_t)2 * b->n_shared, ncclDouble, b->comm,
                                          b->stream));
@@ -1462,6 +1556,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
                 b->ev_triples.push_back({e0, e1, e2});
             }
         }
+        if (fused) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fused, 0));
         b->partial_ptr = saved_partial;
         HIP_TRY(hipGetLastError());
         return HEAT_OK;

@@ -293,6 +293,54 @@ def ragged_mixed(S, Z=None, dt=45.0, seed=20260401, n_lo=8, n_hi=64):
     return md, state
 
 
+def clustered_massive(S, Z=None, dt=45.0, seed=11, n_lo=8, n_hi=40, pair_fraction=0.12):
+    """Ragged fast-path walls in small zone-connected clusters (the cluster-resident march's home ground):
+    75 % all-massive, 25 % massive core between two no-mass facings; most walls Outdoor / Space, some
+    Space / Space between the two zones of a pair (clusters of two zones), some Ambient / Space, some
+    Ambient / Outdoor (coupled to no zone at all)."""
+    rng = np.random.default_rng(seed)
+    Z = Z if Z is not None else max(2, S // 25)
+    md = empty(S, Z, dt)
+    mixed = rng.random(S) >= 0.75
+    n_nodes = rng.integers(n_lo, n_hi + 1, S).astype(np.int64)
+    n_nodes[mixed] = np.maximum(n_nodes[mixed], 4)
+    k, rho_cp, dx = _draw_materials(rng, S, dt)
+    off, surf, local, first, last, mass, u = _massive_nodes(n_nodes, k, rho_cp, dx)
+    u_ins = rng.uniform(0.5, 3.0, S)
+    mx = mixed[surf]
+    second = local == 1
+    before_last = local == (n_nodes[surf] - 2)
+    m_el = (rho_cp * dx)[surf]
+    mass = np.where(mx & (first | last), 0.0, mass)
+    mass = np.where(mx & (second | before_last), m_el / 2., mass)
+    u = np.where(mx & first, u_ins[surf], u)
+    u = np.where(mx & before_last, u_ins[surf], u)
+    md["node_offset"], md["mass"], md["uvalue"] = off, mass, u
+    fa = np.zeros(off[-1]); ba = np.zeros(off[-1])
+    fa[first] = rng.uniform(0.1, 0.9, S)
+    ba[last] = rng.uniform(0.1, 0.9, S)
+    md["front_alpha"], md["back_alpha"] = fa, ba
+    _fill_common(md, rng, S, Z, "outdoor_space")
+    r = rng.random(S)
+    zone_of = md["back_zone"].copy()
+    fk, bk = md["front_kind"], md["back_kind"]
+    pair = r < pair_fraction                      # Space / Space inside a pair of zones (2j, 2j+1)
+    amb = (r >= pair_fraction) & (r < pair_fraction + 0.06)
+    lone = r >= 0.95
+    fk[pair] = SPACE
+    md["front_zone"] = np.where(pair, np.minimum(zone_of ^ 1, Z - 1), zone_of).astype(np.int32)
+    fk[amb | lone] = AMBIENT
+    bk[lone] = OUTDOOR
+    md["front_ambient"] = np.where(fk == AMBIENT, rng.uniform(5, 30, S), 0.0)
+    md["front_emissivity"] = np.where(mixed, md["front_emissivity"] * (0.2 / 0.9), md["front_emissivity"])
+    md["back_emissivity"] = np.where(mixed, md["back_emissivity"] * (0.2 / 0.9), md["back_emissivity"])
+    state = layout_state(md)
+    perturb_initial_temperatures(md, state, rng)
+    state[md["solar_front_slot"]] = rng.uniform(0, 800., S)
+    set_ir_from_air(md, state, 10.0)
+    return md, state
+
+
 def perturb_initial_temperatures(md, state, rng):
     """Spreads the initial temperatures (the reference's all-22.0 start makes every natural
     convection coefficient hit its 0.1 floor, convection.rs:22,91-92)."""

@@ -42,6 +42,7 @@ def main():
             assert np.allclose(got[idx], ref[idx], rtol=1e-9, atol=1e-9)
     forced_shared_zones_single_rank("native")
     forced_shared_zones_single_rank("torch")
+    shared_zones_beside_a_fused_march()
     two_shards_on_one_gpu()
     dist.destroy_process_group()
     print("SHARDED OK")
@@ -77,6 +78,41 @@ def forced_shared_zones_single_rank(collective):
     for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
                 md["flow_back_slot"], md["zone_slot"]):
         assert np.allclose(got[idx], ref[idx], rtol=1e-9, atol=1e-9)
+
+
+def shared_zones_beside_a_fused_march():
+    """Sharded batch whose clusters are fusable: the workgroups that own a shared zone are demoted to the streamed
+    exchange loop (kernel -> ncclAllGather -> kernel every sub-timestep), the others march cluster-resident beside
+    it on a side stream."""
+    md, st = mdl.clustered_massive(1200, Z=48, dt=45.0, seed=3)
+    w = mdl.weather_series(11, 45.0)
+    a0 = np.linspace(0., 30., 48)
+    b0 = np.linspace(0., 1., 48)
+    ref = st.copy()
+    rc, iters = orc.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    sm = ShardedMarch(md, 0, 1, device_index=0, collective="native", force_shared=[3, 20, 21, 47])
+    assert sm.n_shared_zones == 4 and sm.batch.n_fused_surfaces > 0
+    got = st.copy()
+    sm.batch.upload_state(got)
+    sm.march_resident(w[:5], a0, b0)
+    sm.march_resident(w[5:], a0, b0)
+    sm.synchronize()
+    assert sm.batch.nomass_iterations() == iters
+    sm.batch.download_state(got)
+    # the torch collective drives the split-phase calls: everything streamed there
+    sm2 = ShardedMarch(md, 0, 1, device_index=0, collective="torch", force_shared=[3, 20, 21, 47])
+    got2 = st.copy()
+    sm2.batch.upload_state(got2)
+    sm2.march_resident(w, a0, b0)
+    sm2.synchronize()
+    sm2.batch.download_state(got2)
+    sm.close()
+    sm2.close()
+    for g in (got, got2):
+        for idx in (mdl.node_slots(md), md["hs_front_slot"], md["hs_back_slot"], md["flow_front_slot"],
+                    md["flow_back_slot"], md["zone_slot"]):
+            assert np.allclose(g[idx], ref[idx], rtol=1e-9, atol=1e-9)
 
 
 def two_shards_on_one_gpu():

@@ -445,3 +445,59 @@ def test_compiled_cpp_host_on_the_c_abi(oracle):
                     state[md["flow_back_slot"]]], axis=1)
     assert np.allclose(surf, exp, rtol=RTOL, atol=ATOL)
     mb.close()
+
+
+@pytest.mark.parametrize("npl", [0, 4, 8])
+def test_cluster_resident_march_matches_the_oracle_and_the_streamed_march(oracle, npl):
+    """Zone-connected clusters that fit a workgroup march all sub-timesteps of a call in one launch (temperatures in
+    registers, zone balance in LDS); the others are streamed beside them. Same results as the oracle (1e-9) and as
+    the all-streamed march (no_fusion), also when the march is cut into several calls."""
+    md, st = mdl.clustered_massive(1500, Z=60, dt=45.0, seed=11 + npl)
+    w = mdl.weather_series(23, 45.0, wind_speed=3.5, wind_deg=120.0)
+    a0 = np.linspace(0., 60., 60)
+    b0 = np.linspace(0., 2., 60)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    got = st.copy()
+    with HeatBatch(md, nodes_per_lane=npl) as b:
+        nf = b.n_fused_surfaces
+        assert 0 < nf < md["n_surfaces"]          # both kinds of clusters are present
+        b.upload_state(got)
+        b.march(got, w[:9], a0, b0)               # one launch of 9 sub-timesteps ...
+        b.march(got, w[9:10], a0, b0)             # ... of one ...
+        b.march(got, w[10:], a0, b0)              # ... of 13
+        assert b.nomass_iterations() == iters
+    assert_state_close(md, ref, got)
+    streamed = st.copy()
+    with HeatBatch(md, nodes_per_lane=npl, no_fusion=True) as b:
+        assert b.n_fused_surfaces == 0
+        b.upload_state(streamed)
+        b.march(streamed, w, a0, b0)
+    assert np.allclose(got, streamed, rtol=1e-11, atol=1e-11)
+    # switched off at run time: the same layout, everything streamed
+    off = st.copy()
+    with HeatBatch(md, nodes_per_lane=npl, use_graph=True) as b:
+        b.set_fusion(False)
+        b.upload_state(off)
+        b.march(off, w, a0, b0)
+    assert np.allclose(got, off, rtol=1e-11, atol=1e-11)
+
+
+def test_cluster_resident_march_config2_and_lone_surfaces(oracle):
+    # BASELINE config 2 (identical massive walls, 100 per zone): every cluster fused; plus walls that face no zone
+    md, st = mdl.uniform_massive(400, 20, Z=4, dt=90.0, identical=True, vertical=True)
+    w = mdl.weather_series(50, 90.0)
+    ref, got, _, _, counts = run_both(oracle, md, st, w)
+    assert_state_close(md, ref, got)
+    with HeatBatch(md) as b:
+        assert b.n_fused_surfaces == 400
+    md, st = mdl.uniform_massive(300, 24, Z=3, dt=45.0, seed=5)
+    md["back_kind"][:] = mdl.OUTDOOR      # Outdoor on both sides: coupled to no zone
+    md["front_kind"][::3] = mdl.AMBIENT
+    md["front_ambient"][::3] = 17.5
+    w = mdl.weather_series(30, 45.0)
+    ref, got, _, _, counts = run_both(oracle, md, st, w)
+    assert_state_close(md, ref, got)
+    with HeatBatch(md) as b:
+        assert b.n_fused_surfaces == 300
