@@ -195,6 +195,7 @@ struct heat_batch {
 
     DevBuf<int32_t> d_meta;        // node count per device surface (upload/download kernels)
     DevBuf<SideConst> d_side_const;  // [2 * S]: front records, then back records
+    DevBuf<double> d_side_alpha;     // [2 * S]: factor applied to the solar irradiance at upload (layout.hpp, SideDyn)
     DevBuf<SideDyn> d_side_dyn;      // [2 * S]
     DevBuf<SideOut> d_side_out;      // [2 * S]
     DevBuf<double> d_hs_fix;         // [2 * S] or empty
@@ -474,8 +475,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     // lives across sub-timesteps). Surfaces that face no zone at all are clusters of one and are packed freely.
     struct BlockPlan { int cls; std::vector<int32_t> zones; };
     std::vector<BlockPlan> blocks;
-    const bool fuse = !opt.no_fusion && !opt.force_general && !opt.no_palette &&
-                      (opt.nodes_per_lane == 0 || opt.nodes_per_lane == 4 || opt.nodes_per_lane == 8);
+    const bool fuse = !opt.no_fusion && !opt.force_general && !opt.no_palette;
     if (fuse && S > 0) {
         auto fusable = [&](int64_t s) { return cat[s].kind == 0 && cat[s].pal && cat[s].ncav == 0; };
         auto zone_of_side = [&](int64_t s, int side) -> int32_t {
@@ -524,18 +524,30 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             blocks.push_back(BlockPlan{cls, {}});
             return (int)blocks.size() - 1;
         };
-        const int ms_all[2] = {4, 8};
+        // The cluster-resident kernels are bound by instruction issue, not by HBM: cost per padded node by
+        // measured VALU instructions per node and sub-timestep (M = 16 : 8 : 4 = 0.76 : 1.11 : 1.9).
+        auto fused_cost = [&](int n, int m) {
+            const double w = (m == 4) ? 2.5 : (m == 8 ? 1.46 : 1.00);
+            return (double)((n + m - 1) / m * m) * w;
+        };
+        const int ms_all[3] = {4, 8, 16};
         for (int64_t r = 0; r < Z; r++) {
             if (find((int32_t)r) != r || !cok[r] || coff[r + 1] == coff[r]) continue;
-            // one blocking factor for the cluster: the cheaper of 4 and 8 nodes per lane
+            // one blocking factor for the cluster: the cheapest that keeps every surface at two lanes or more
             int M = opt.nodes_per_lane;
             if (M == 0) {
                 double best = 0.0;
                 for (int m : ms_all) {
                     double c = 0.0;
-                    for (int64_t q = coff[r]; q < coff[r + 1]; q++) c += padded_cost(placed[csurf[q]].n, m);
-                    if (M == 0 || c < best) { M = m; best = c; }
+                    bool ok = true;
+                    for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                        const int n = placed[csurf[q]].n;
+                        ok = ok && (n + m - 1) / m >= 2;
+                        c += fused_cost(n, m);
+                    }
+                    if (ok && (M == 0 || c < best)) { M = m; best = c; }
                 }
+                if (M == 0) M = 4;
             }
             int nm = 0, cnt[kWave + 1] = {}, ne = 0;
             bool fits = true;
@@ -554,7 +566,10 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             Open &o = open[cls];
             int merged[kWave + 1];
             for (int k = 0; k <= kWave; k++) merged[k] = o.cnt[k] + cnt[k];
-            if (o.blk < 0 || tiles_needed(merged) > kFusedMaxWaves || o.nz + nz > kFusedMaxZones ||
+            // Workgroups of four tiles are the target (two of them share a compute unit, so one's zone balance —
+            // a short serial section — overlaps the other's stencil work): clusters are merged only up to four
+            // tiles; a cluster that needs five to eight gets a workgroup of its own.
+            if (o.blk < 0 || tiles_needed(merged) > 4 || o.nz + nz > kFusedMaxZones ||
                 o.ne + ne > kFusedMaxEntries) {
                 o = Open();
                 o.blk = new_block(cls);
@@ -580,9 +595,12 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         for (int64_t s : lone) {
             Placed &pl = placed[s];
             int M = opt.nodes_per_lane;
-            if (M == 0) M = padded_cost(pl.n, 8) < padded_cost(pl.n, 4) ? 8 : 4;
+            if (M == 0) {
+                M = 4;
+                for (int m : {8, 16})
+                    if ((pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) < fused_cost(pl.n, M)) M = m;
+            }
             int k = (pl.n + M - 1) / M;
-            if (k < 2 && opt.nodes_per_lane == 0 && pl.n > 4) { M = 4; k = (pl.n + M - 1) / M; }
             if (k > kWave || k < 2) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, 0, 1});
             pl.k = k;
@@ -779,6 +797,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     // ---- per-side records (device order) ----
     std::vector<int32_t> hMeta(S);
     std::vector<SideConst> hSide(2 * S);
+    std::vector<double> hAlpha(2 * S, 1.0);
     std::vector<double> hFix;
     std::vector<int64_t> hFirst(S), hSlots(8 * S);
     const bool has_fix = d->front_hs_fix != nullptr;
@@ -804,6 +823,21 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             c.alpha = side ? d->back_alpha[o + n - 1] : d->front_alpha[o];
             // front Outdoor flips the sign (surface.rs:652); back Outdoor does not (surface.rs:689-696)
             c.cos_eff = (side == 0 && kind == HEAT_BOUNDARY_OUTDOOR) ? -cos_tilt : cos_tilt;
+            hAlpha[(int64_t)side * S + dd] = 1.0;
+            if (placed[s].cls < kNumFast) {
+                // fast classes: the absorptance goes into SideDyn::solar at upload; the two slots carry the TARP
+                // natural-convection coefficients of convection.rs:87-110 with the tilt-dependent division done here
+                hAlpha[(int64_t)side * S + dd] = c.alpha;
+                const double ce = c.cos_eff, act = std::fabs(ce);
+                const double up = 9.482 / (7.238 - act), down = 1.81 / (1.382 + act);
+                double pos, neg;  // air warmer / colder than the surface
+                if (ce != ce) { pos = neg = ce; }
+                else if (act < 1e-3) { pos = neg = 1.31; }
+                else if (ce > 0.) { pos = up; neg = down; }
+                else { pos = down; neg = up; }
+                c.cos_eff = pos;
+                c.alpha = neg;
+            }
             c.forced = kind == HEAT_BOUNDARY_OUTDOOR ? forced : 0.0;
             c.nx = d->normal_x[s];
             c.ny = d->normal_y[s];
@@ -962,6 +996,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     }
     HIP_TRY(b->d_meta.upload(hMeta));
     HIP_TRY(b->d_side_const.upload(hSide));
+    HIP_TRY(b->d_side_alpha.upload(hAlpha));
     if (has_fix) HIP_TRY(b->d_hs_fix.upload(hFix));
     HIP_TRY(b->d_side_dyn.zeros(2 * S));
     HIP_TRY(b->d_side_out.zeros(2 * S));
@@ -1243,8 +1278,8 @@ static int transfer_in(heat_batch *b, const double *state, size_t n_state, bool 
         launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p,
                              b->d_state.p, 0, b->stream);
     }
-    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_state.p, 0, full ? 3 : 1,
-                        b->stream);
+    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_side_alpha.p, b->d_state.p, 0,
+                        full ? 3 : 1, b->stream);
     launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 0, b->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1268,7 +1303,8 @@ int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
                           b->d_first_slot.p, b->d_state.p, 1, b->stream);
     launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p, b->d_state.p,
                          1, b->stream);
-    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_state.p, 1, 2, b->stream);
+    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_side_alpha.p, b->d_state.p, 1, 2,
+                        b->stream);
     launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 1, b->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->stream));

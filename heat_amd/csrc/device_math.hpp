@@ -30,6 +30,23 @@ __device__ __forceinline__ double tarp_natural(double air_t, double surf_t, doub
     return (h < 0.1) ? 0.1 : h;  // MIN_H, convection.rs:22,105-109
 }
 
+// The same with the tilt-dependent factors taken out (fast classes): nat_pos / nat_neg = h / |dT|^(1/3) for air
+// warmer / colder than the surface, set up on the host from the branches above. c3 * (9.482 / (7.238 - |cos|))
+// instead of (9.482 * c3) / (7.238 - |cos|): one rounding more, two divisions less per evaluation.
+__device__ __forceinline__ double tarp_natural_coef(double air_t, double surf_t, double nat_pos, double nat_neg, int &bad) {
+    const double delta_t = air_t - surf_t;
+    const double adt = fabs(delta_t);
+    const double c3 = cbrt(adt);
+    double coef = (delta_t > 0.) ? nat_pos : nat_neg;
+    if (adt < 1e-3) coef = 1.31;
+    if (delta_t != delta_t || nat_pos != nat_pos) {  // unreachable!() in the reference (NaN temperatures / tilt)
+        bad |= FLAG_UNREACHABLE;
+        coef = __builtin_nan("");
+    }
+    const double h = coef * c3;
+    return (h < 0.1) ? 0.1 : h;  // MIN_H, convection.rs:22,105-109
+}
+
 // Forced component of the TARP exterior coefficient — reference src/convection.rs:151-168
 // with roughness_index == 1 -> COEFFICIENTS[1] = 1.67 (surface.rs:618,633,649).
 __device__ __forceinline__ double tarp_forced(double air_speed, double area, double perimeter, bool windward) {

@@ -105,9 +105,9 @@ __device__ __forceinline__ double from_next_lane(double v) { return dpp_rotate_f
 //   STAGE 2: in = out      acc += k/3        out = T + k
 //   STAGE 3: in = out                        out = acc + k/6   (the new temperatures)
 // FULL: every surface of the tile fills its last lane (n == k M), so the last node is j == M-1.
-template <int M, bool FULL, int STAGE>
+template <int M, bool FULL, int STAGE, typename VF>
 __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in)[M], double (&out)[M],
-                                         double (&acc)[M], const double (&V)[M], const double (&U)[M], double UL,
+                                         double (&acc)[M], VF V, const double (&U)[M], double UL,
                                          bool is_first, bool is_last, int jl, double hF, double qF, double hB,
                                          double qB, int lane) {
     double xl = from_prev_lane(in[M - 1]);
@@ -128,7 +128,7 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
         } else {
             f = (is_last && j == jl) ? (qB - hB * xj) : f;
         }
-        const double k = V[j] * (f - fprev);
+        const double k = V(j) * (f - fprev);
         fprev = f;
         if (STAGE == 0) { acc[j] = T[j] + k * (1.0 / 6.0); out[j] = T[j] + 0.5 * k; }
         if (STAGE == 1) { acc[j] += k * (1.0 / 3.0); out[j] = T[j] + 0.5 * k; }
@@ -166,10 +166,14 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     extern __shared__ double s_dyn[];
     __shared__ double s_pal_static[(PAL && !FUSED) ? kLanes * kPal : 2];
     double *const s_pal = FUSED ? s_dyn : s_pal_static;
-    // FUSED, after the palettes: (hs * area, face temperature) per side [2][kLanes] double2; zone temperatures,
-    // a0, b0, volume [kFusedMaxZones] each; first slot of every zone [kFusedMaxZones + 1]; the slot lists.
-    double2 *const s_hT = reinterpret_cast<double2 *>(s_dyn + kLanes * kPal);
-    double *const s_zT = s_dyn + kLanes * kPal + 4 * kLanes;
+    // FUSED, after the palettes: with 16 nodes per lane V = dt/C of every node, [M][kLanes] (read where it is used:
+    // held in registers over the march it would push that variant out of the register file); (hs * area, face temperature)
+    // per side [2][kLanes] double2; zone temperatures, a0, b0, volume [kFusedMaxZones] each; first slot of every
+    // zone [kFusedMaxZones + 1]; the slot lists.
+    constexpr bool kVinLds = FUSED && M == 16;
+    double *const s_V = s_dyn + kLanes * kPal;
+    double2 *const s_hT = reinterpret_cast<double2 *>(s_V + (kVinLds ? M : 0) * kLanes);
+    double *const s_zT = reinterpret_cast<double *>(s_hT) + 4 * kLanes;
     double *const s_za0 = s_zT + kFusedMaxZones;
     double *const s_zb0 = s_za0 + kFusedMaxZones;
     double *const s_zvol = s_zb0 + kFusedMaxZones;
@@ -211,8 +215,9 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const bool is_last = (seg == k - 1);
     const bool my_back = !is_first;
     const int sidx = (my_back ? S : 0) + d;
-    const SideConst c = sd.sc[sidx];
-    const SideDyn dy = sd.dyn[sidx];
+    const SideConst c_load = sd.sc[sidx];
+    const SideDyn dy_load = sd.dyn[sidx];
+    const int kind_n_mine = c_load.kind_n;
     // (FUSED workgroups hold surfaces of two or more lanes only — the host sees to it — so the "this lane owns
     // both sides" path of single-lane surfaces is not compiled into them.)
     int my_lz = 0;
@@ -254,7 +259,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             T[2 * jp] = t.x; T[2 * jp + 1] = t.y;
         }
         __builtin_amdgcn_wave_barrier();  // LDS writes above are ordered before the reads below (same wave)
-        if constexpr (!FUSED) {
+        {
             const double *mp = sp + g * kPal;
 #pragma unroll
             for (int j = 0; j < M; j++) {
@@ -262,6 +267,10 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 V[j] = mp[cbj & (kPalV - 1)];
                 U[j] = mp[kPalV + (cbj >> 3)];
             }
+        }
+        if constexpr (kVinLds) {
+#pragma unroll
+            for (int j = 0; j < M; j++) s_V[j * kLanes + threadIdx.x] = V[j];
         }
     } else {
         const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
@@ -294,7 +303,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 
     const int first_lane = g * k;
     const int last_lane = min(g * k + k - 1, kWave - 1);
-    const int nn = c.kind_n >> 16;
+    const int nn = kind_n_mine >> 16;
     const int jl = full ? (M - 1) : (nn - 1 - (k - 1) * M);  // local index of the last node inside the last lane
 
     auto pick_last = [&](const double (&x)[M]) {
@@ -308,14 +317,28 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
 
     int4 cavref = make_int4(-1, -1, -1, -1);
     if constexpr (CAV) cavref = reinterpret_cast<const int4 *>(na.cavref)[d];
-    SideConst cb2 = c;
-    SideDyn db2 = dy;
+    SideConst cb2 = c_load;
+    SideDyn db2 = dy_load;
     if constexpr (!FUSED) {
         if (k == 1) {  // single-lane surfaces: this lane is also the last one
             cb2 = sd.sc[S + d];
             db2 = sd.dyn[S + d];
         }
     }
+
+    // V = dt/C of local node j: registers, or the workgroup's LDS array (FUSED with 16 nodes per lane)
+    auto Vat = [&](int j) -> double {
+        if constexpr (kVinLds) return s_V[j * kLanes + threadIdx.x];
+        else return V[j];
+    };
+    auto V_last = [&]() {
+        double r = Vat(M - 1);
+        if (!full) {
+#pragma unroll
+            for (int j = 0; j < M - 1; j++) r = (j == jl) ? Vat(j) : r;
+        }
+        return r;
+    };
 
     int bad_all = 0;
     unsigned int nm_passes = 0;
@@ -327,19 +350,12 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     for (int it = 0; it < n_it; it++) {  // sub-timesteps (one, unless FUSED)
     const StepWeather w = w_next;
     if constexpr (FUSED) w_next = weather[min(it + 1, n_it - 1)];  // fetched a whole sub-timestep ahead of its use
-    if constexpr (FUSED) {  // V = dt/C and U of this lane's nodes, from the tile's palettes in LDS
-        const double *mp = s_pal + wib * (kWave * kPal) + g * kPal;
-        // (opaque to the optimiser: otherwise the 2 M palette addresses are hoisted out of the sub-timestep loop
-        // and held in registers for the whole march)
-#pragma unroll
-        for (int q = 0; q < M / 4; q++) asm volatile("" : "+v"(cw[q]));
-#pragma unroll
-        for (int j = 0; j < M; j++) {
-            const unsigned int cbj = (cw[j >> 2] >> (8 * (j & 3))) & 0xff;
-            V[j] = mp[cbj & (kPalV - 1)];
-            U[j] = mp[kPalV + (cbj >> 3)];
-        }
-    }
+    // The side record: FUSED fetches it again every sub-timestep (an L1/L2 hit) instead of holding its 20
+    // registers across the march.
+    int sidx_now = sidx;
+    if constexpr (FUSED) asm volatile("" : "+v"(sidx_now));
+    const SideConst c = FUSED ? sd.sc[sidx_now] : c_load;
+    const SideDyn dy = FUSED ? sd.dyn[sidx_now] : dy_load;
     // get_boundary_temperature, model.rs:79-96 (FUSED: zone temperatures live in LDS)
     auto btemp = [&](const SideConst &cc, int lz) -> double {
         const int kind = cc.kind_n & 3;
@@ -376,8 +392,8 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         }
         fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
     };
-    auto conv = [&](double air_t, double forced, double cos_eff, double fix, double surf_t) {
-        double hs = forced + tarp_natural(air_t, surf_t, cos_eff, bad);  // convection.rs:165-167
+    auto conv = [&](double air_t, double forced, double nat_pos, double nat_neg, double fix, double surf_t) {
+        double hs = forced + tarp_natural_coef(air_t, surf_t, nat_pos, nat_neg, bad);  // convection.rs:165-167
         if (hs != hs) bad |= FLAG_NAN_HS;                                // surface.rs:704-707
         if (fix == fix) hs = fix;
         return hs;
@@ -403,14 +419,14 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         h_out = 0.0;
         q_out = 0.0;
         const double surf_t = (back && !use_front_T) ? Tn : T0;
-        const double hs = conv(air_t, forced, cc.cos_eff, fix, surf_t);
+        const double hs = conv(air_t, forced, cc.cos_eff, cc.alpha, fix, surf_t);  // (fast classes: the two coefficients)
         const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
-        const double sol = cc.alpha * dd.solar;
+        const double sol = dd.solar;                        // absorbed: alpha * irradiance, formed at upload
         if constexpr (NM) {
             // One-node no-mass chunk at this face (discretization.rs:658-697 for nnodes == 1):
             //   K = (0 - h_face) - u_inner,  q = (q_face + u_inner * T_inner) + solar,  x = -q / K,
             //   T <- (T + x) / 2 until the error stops shrinking or err < tol (surface.rs:836-895).
-            const double vface = back ? pick_last(V) : V[0];
+            const double vface = back ? V_last() : Vat(0);
             if (active && vface == 0.0 && nn >= 2) {
                 double u_in, t_in;
                 if (!back) {
@@ -471,13 +487,14 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         hB = my_back ? h_ : 0.0;
         qB = my_back ? q_ : 0.0;
     }
-    double b_air = 0.0, b_forced = 0.0, b_fix = 0.0, b_cos = 0.0;
+    double b_air = 0.0, b_forced = 0.0, b_fix = 0.0, b_cos = 0.0, b_neg = 0.0;
     bool b_useF = false;
     if constexpr (!FUSED) {
         if (k == 1) {  // single-lane surfaces: this lane is also the last one
             double b_rad;
             prepare(cb2, db2, true, S + d, 0, b_air, b_rad, b_forced, b_fix, b_useF);
             b_cos = cb2.cos_eff;
+            b_neg = cb2.alpha;
             add_face(cb2, db2, true, b_air, b_rad, b_forced, b_fix, b_useF, hB, qB);
         }
     }
@@ -508,15 +525,15 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // ---- RK4 (surface.rs:228-308) ----
     double acc[M];
     if (full) {
-        rk_stage<M, true, 0>(T, T, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, true, 1>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, true, 2>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, true, 3>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 0>(T, T, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 1>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 2>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 3>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     } else {
-        rk_stage<M, false, 0>(T, T, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, false, 1>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, false, 2>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, false, 3>(T, aux, aux, acc, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 0>(T, T, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 1>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 2>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 3>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     }
 
     // ---- write back node temperatures (model.rs:145-147); FUSED: after the last sub-timestep only ----
@@ -534,7 +551,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const double Tnn = shfl_f64(Tln, last_lane);
     {
         const double surf_t = (my_back && !my_useF) ? Tnn : T0n;
-        const double hs = conv(my_air, my_forced, c.cos_eff, my_fix, surf_t);
+        const double hs = conv(my_air, my_forced, c.cos_eff, c.alpha, my_fix, surf_t);
         const double face_t = my_back ? Tln : aux[0];
         o_hs = hs;
         o_flow = (face_t - my_air) * hs;
@@ -544,7 +561,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         }
     }
     if (!FUSED && k == 1) {
-        const double hs = conv(b_air, b_forced, b_cos, b_fix, b_useF ? T0n : Tnn);
+        const double hs = conv(b_air, b_forced, b_cos, b_neg, b_fix, b_useF ? T0n : Tnn);
         o2_hs = hs;
         o2_flow = (Tln - b_air) * hs;
     } else if (!(is_first || is_last)) {
@@ -1147,7 +1164,7 @@ k_nodes_general(const GeneralTile *__restrict__ tiles, int n_tiles, double *__re
 // what: bit 0 inputs (solar, ir), bit 1 outputs (hs, flow)
 __global__ void __launch_bounds__(256)
 k_surf_scalars(int n_surf, SlotArrays sl, SideDyn *__restrict__ dyn, SideOut *__restrict__ out,
-               double *__restrict__ state, int to_state, int what) {
+               const double *__restrict__ side_alpha, double *__restrict__ state, int to_state, int what) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_surf) return;
     const int S = n_surf;
@@ -1168,9 +1185,9 @@ k_surf_scalars(int n_surf, SlotArrays sl, SideDyn *__restrict__ dyn, SideOut *__
             double sb = state[sl.solar_b[d]];
             if (sb != sb) sb = 0.0;
             SideDyn f, b;
-            f.solar = sf;
+            f.solar = sf * side_alpha[d];      // fast classes: absorbed by the face node; others: factor 1
             f.rad_t = ir_to_rad_temperature(state[sl.ir_f[d]]);
-            b.solar = sb;
+            b.solar = sb * side_alpha[S + d];
             b.rad_t = ir_to_rad_temperature(state[sl.ir_b[d]]);
             dyn[d] = f;
             dyn[S + d] = b;
@@ -1244,8 +1261,8 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
 
 // Cluster-resident march of one class: one workgroup of `max_waves` (4 or 8) wavefronts per FusedBlock, fa.n_sub
 // sub-timesteps in one launch. Palette classes without cavities only.
-size_t fused_lds_bytes(int max_waves) {
-    return (size_t)max_waves * kWave * (kPal * sizeof(double) + 2 * sizeof(double2)) +
+size_t fused_lds_bytes(int max_waves, int M) {
+    return (size_t)max_waves * kWave * ((kPal + (M == 16 ? M : 0)) * sizeof(double) + 2 * sizeof(double2)) +
            4 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
 }
 
@@ -1253,7 +1270,7 @@ template <int MM, int NN, int FW>
 static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                                    const SideArrays &sa, const StepWeather *weather, int *flags,
                                    unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
-    const size_t lds = fused_lds_bytes(FW);
+    const size_t lds = fused_lds_bytes(FW, MM);
     static bool attr_set = false;  // (per instantiation) dynamic LDS above the 64 KB default needs the attribute
     if (!attr_set) {
         if (lds > 64 * 1024) {
@@ -1350,11 +1367,11 @@ void launch_nodes_general(const GeneralTile *tiles, int n_tiles, double *Tbuf, c
                        meta, first_slot, state, to_state);
 }
 
-void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, double *state, int to_state,
-                         int what, hipStream_t st) {
+void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, const double *side_alpha,
+                         double *state, int to_state, int what, hipStream_t st) {
     if (n_surf <= 0) return;
-    hipLaunchKernelGGL(k_surf_scalars, dim3((n_surf + 255) / 256), dim3(256), 0, st, n_surf, sl, dyn, out, state,
-                       to_state, what);
+    hipLaunchKernelGGL(k_surf_scalars, dim3((n_surf + 255) / 256), dim3(256), 0, st, n_surf, sl, dyn, out, side_alpha,
+                       state, to_state, what);
 }
 
 void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, double *state, int to_state,

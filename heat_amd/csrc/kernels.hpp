@@ -39,8 +39,8 @@ void launch_nodes_fast(int M, const FastTile *tiles, int n_tiles, double *Tbuf, 
                        const int64_t *first_slot, double *state, int to_state, hipStream_t st);
 void launch_nodes_general(const GeneralTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
                           const int64_t *first_slot, double *state, int to_state, hipStream_t st);
-void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, double *state, int to_state,
-                         int what, hipStream_t st);
+void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, const double *side_alpha,
+                         double *state, int to_state, int what, hipStream_t st);
 void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, double *state, int to_state,
                          hipStream_t st);
 void launch_set_step(int *step_ptr, int v, hipStream_t st);

@@ -56,14 +56,19 @@ struct alignas(16) SideConst {
     int32_t zone;     // zone index when kind == KIND_SPACE
     double ambient;   // Boundary::AmbientTemperature { temperature }
     double emis;      // thermal emissivity of this face (src/surface.rs:335,338)
-    double alpha;     // solar absorptance of the face node (front_alphas[0] / back_alphas[n-1])
-    double cos_eff;   // cos_surface_tilt as this side's ConvectionParams takes it (front Outdoor: -cos)
+    double alpha;     // general / small classes: solar absorptance of the face node (front_alphas[0] / back_alphas[n-1]).
+                      // FAST classes: TARP natural-convection coefficient for air COLDER than the surface, h / |dT|^(1/3)
+                      // (the absorptance is folded into SideDyn::solar at upload)
+    double cos_eff;   // general / small classes: cos_surface_tilt as this side's ConvectionParams takes it (front
+                      // Outdoor: -cos). FAST classes: the coefficient for air WARMER than the surface. Both are
+                      // 1.31, 9.482 / (7.238 - |cos|) or 1.81 / (1.382 + |cos|) by the branches of convection.rs:87-110.
     double forced;    // 2.537 * 1.67 * sqrt(perimeter * wind_modifier / area)  (src/convection.rs:157-163)
     double nx, ny;    // surface normal (for is_windward)
 };
 // Inputs other modules write between marches, converted once at upload.
 struct alignas(16) SideDyn {
-    double solar;     // incident solar irradiance, clamped as src/surface.rs:916-923 does
+    double solar;     // incident solar irradiance, clamped as src/surface.rs:916-923 does; FAST classes: times the
+                      // face absorptance (the only node that absorbs on the fast path)
     double rad_t;     // (ir / sigma)^0.25 - 273.15 (src/surface.rs:647,692)
 };
 // Outputs of iterate_surfaces (src/model.rs:154-169).

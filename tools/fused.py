@@ -9,7 +9,7 @@ P = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 md, st = mdl.uniform_massive(S, n, Z=max(1, S // 100), dt=45.0)
 w = mdl.weather_series(P, 45.0)
 res = {}
-for npl in (0, 4, 8):
+for npl in (0, 8, 16):
     with HeatBatch(md, nodes_per_lane=npl) as b:
         print("npl", npl, "classes", b.class_counts(), "fused surfaces", b.n_fused_surfaces, flush=True)
         for fused in (False, True):
