@@ -302,7 +302,6 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     }
 
     const int first_lane = g * k;
-    const int last_lane = min(g * k + k - 1, kWave - 1);
     const int nn = kind_n_mine >> 16;
     const int jl = full ? (M - 1) : (nn - 1 - (k - 1) * M);  // local index of the last node inside the last lane
 
@@ -315,6 +314,9 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         return r;
     };
 
+    // does any back side of this tile face an ambient temperature? (wave-uniform)
+    const bool wave_quirk = __any((is_last && (kind_n_mine & 3) == KIND_AMBIENT && my_back) ||
+                                  (k == 1 && (sd.sc[S + d].kind_n & 3) == KIND_AMBIENT));
     int4 cavref = make_int4(-1, -1, -1, -1);
     if constexpr (CAV) cavref = reinterpret_cast<const int4 *>(na.cavref)[d];
     SideConst cb2 = c_load;
@@ -399,9 +401,11 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         return hs;
     };
 
-    // Surface temperatures as the reference reads them from `state` (pre-step).
-    const double T0 = shfl_f64(T[0], first_lane);
-    const double Tn = shfl_f64(pick_last(T), last_lane);
+    // Surface temperatures as the reference reads them from `state` (pre-step). A side reads its own face node,
+    // which its owner lane holds; only a back side facing an ambient temperature reads the FRONT node
+    // (surface.rs:672-686) and needs it from the surface's first lane.
+    const double T0 = wave_quirk ? shfl_f64(T[0], first_lane) : T[0];
+    const double Tn = pick_last(T);
 
     // Conductance towards the previous lane's last node.
     double UL = from_prev_lane(U[M - 1]);
@@ -546,9 +550,9 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     }
 
     // ---- convection coefficients with the NEW temperatures + heat flows (model.rs:150-169) ----
-    const double T0n = shfl_f64(aux[0], first_lane);
+    const double T0n = wave_quirk ? shfl_f64(aux[0], first_lane) : aux[0];
     const double Tln = pick_last(aux);
-    const double Tnn = shfl_f64(Tln, last_lane);
+    const double Tnn = Tln;
     {
         const double surf_t = (my_back && !my_useF) ? Tnn : T0n;
         const double hs = conv(my_air, my_forced, c.cos_eff, c.alpha, my_fix, surf_t);
