@@ -65,14 +65,16 @@ def march_series(oracle, md, state, n_sub, fx, emissivity, area=60.0, march=None
     return found
 
 
-CASES = {
-    # dir: (layers, emissivity, solar absorptance) — validate_wall_heat_transfer.rs:817-994
-    "massive_no_ir_no_solar": ([dict(thickness=0.2, **CONCRETE)], 0.0, 0.0),
-    "massive_full": ([dict(thickness=0.2, **CONCRETE)], 0.9, 0.7),
-    "mixed_no_ir_no_solar": ([dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400.), dict(thickness=0.2, **CONCRETE),
-                              dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400.)], 0.0, 0.0),
-    "nomass_no_ir_no_solar": ([dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400.)], 0.0, 0.0),
+_POLY = dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400.)
+_CONSTRUCTIONS = {
+    "massive": [dict(thickness=0.2, **CONCRETE)],
+    "mixed": [dict(_POLY), dict(thickness=0.2, **CONCRETE), dict(_POLY)],
+    "nomass": [dict(_POLY)],
 }
+_RADIATION = {"full": (0.9, 0.7), "no_ir_no_solar": (0.0, 0.0), "no_ir_yes_solar": (0.0, 0.7), "yes_ir_no_solar": (0.9, 0.0)}
+# dir: (layers, emissivity, solar absorptance) — the twelve cases of validate_wall_heat_transfer.rs:817-994
+CASES = {"%s_%s" % (c, r): (_CONSTRUCTIONS[c], _RADIATION[r][0], _RADIATION[r][1])
+         for c in _CONSTRUCTIONS for r in _RADIATION}
 
 
 def test_config1_discretization_is_as_surveyed(oracle):
@@ -90,8 +92,14 @@ def test_config1_discretization_is_as_surveyed(oracle):
     assert d["n_elements"] == [0] and d["n_nodes"] == 2
 
 
-@pytest.mark.parametrize("case,max_rmse", [("massive_no_ir_no_solar", 0.1), ("massive_full", 0.25),
-                                           ("mixed_no_ir_no_solar", 0.1), ("nomass_no_ir_no_solar", 0.4)])
+# RMSE of the zone temperature against EnergyPlus over rows 5001..7000, measured with this oracle (°C):
+#   massive: full 0.077, no_ir_no_solar 0.033, no_ir_yes_solar 0.066, yes_ir_no_solar 0.052
+#   mixed:   full 0.059, no_ir_no_solar 0.028, no_ir_yes_solar 0.255, yes_ir_no_solar 0.102
+#   nomass:  full 0.265, no_ir_no_solar 0.133, no_ir_yes_solar 0.230, yes_ir_no_solar 0.190
+@pytest.mark.parametrize("case,max_rmse", [
+    ("massive_full", 0.15), ("massive_no_ir_no_solar", 0.1), ("massive_no_ir_yes_solar", 0.15), ("massive_yes_ir_no_solar", 0.1),
+    ("mixed_full", 0.12), ("mixed_no_ir_no_solar", 0.1), ("mixed_no_ir_yes_solar", 0.4), ("mixed_yes_ir_no_solar", 0.2),
+    ("nomass_full", 0.4), ("nomass_no_ir_no_solar", 0.25), ("nomass_no_ir_yes_solar", 0.4), ("nomass_yes_ir_no_solar", 0.3)])
 def test_zone_temperature_tracks_energyplus(oracle, case, max_rmse):
     layers, emis, sol = CASES[case]
     fx = np.load(os.path.join(GOLD, "wall_%s.npz" % case))

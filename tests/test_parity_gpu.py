@@ -178,7 +178,8 @@ def test_error_codes(oracle):
         assert e.value.code > 0  # numerical failure, like the reference's panic
 
 
-@pytest.mark.parametrize("case", ["massive_no_ir_no_solar", "mixed_no_ir_no_solar", "nomass_no_ir_no_solar", "massive_full"])
+@pytest.mark.parametrize("case", ["massive_no_ir_no_solar", "mixed_no_ir_no_solar", "nomass_no_ir_no_solar", "massive_full",
+                                  "mixed_full", "nomass_full", "massive_no_ir_yes_solar", "mixed_yes_ir_no_solar"])
 def test_config1_energyplus_series_through_the_abi(oracle, case):
     """BASELINE config 1 (and its mixed / no-mass / full-radiation siblings): the reference's validation
     harness (validate_wall_heat_transfer.rs:615-711) driven through heat_batch_march, step by step with
