@@ -120,6 +120,7 @@ struct DevBuf {
 };
 
 constexpr int kMaxNodesGeneral = 4096;
+constexpr int kFusedMinSubsteps = 3;  // march calls of fewer sub-timesteps are streamed
 constexpr int kScratchArrays = 7;
 // fast classes: index = mi * 6 + nm * 3 + v;  M = 4 << mi;  nm: no-mass facings allowed;
 // v = 0 per-node arrays, 1 palette constants, 2 palette + gas cavities between massive nodes
@@ -142,6 +143,7 @@ struct heat_batch {
     // the sub-timestep graph as parallel branches).
     static constexpr int kSideStreams = 3;
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
+    hipStream_t fused_stream = nullptr;  // the cluster-resident march when other surfaces are streamed beside it
     hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr};
     int n_ranks = 1, rank = 0;
     bool use_graph = false;
@@ -259,6 +261,7 @@ struct heat_batch {
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
             if (side[i]) (void)hipStreamDestroy(side[i]);
         }
+        if (fused_stream) (void)hipStreamDestroy(fused_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_fused) (void)hipEventDestroy(ev_fused);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -1234,6 +1237,8 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
                 hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess)
                 rc = fail(HEAT_E_DEVICE, "side stream creation failed");
         }
+        if (!rc && hipStreamCreateWithFlags(&b->fused_stream, hipStreamNonBlocking) != hipSuccess)
+            rc = fail(HEAT_E_DEVICE, "side stream creation failed");
         if (!rc && (hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&b->ev_fused, hipEventDisableTiming) != hipSuccess))
             rc = fail(HEAT_E_DEVICE, "event creation failed");
@@ -1552,9 +1557,9 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         // The clusters that own no shared zone march beside the exchange loop, in one launch per class on a side
         // stream: only the few surfaces around the shared zones go through kernel -> all-gather -> kernel every
         // sub-timestep, and that chain is shorter than the fused march it runs next to.
-        const bool fused = b->any_fused && b->fusion_on && n_sub > 0 && b->side[2] != nullptr;
+        const bool fused = b->any_fused && b->fusion_on && n_sub >= kFusedMinSubsteps && b->fused_stream != nullptr;
         if (fused) {
-            hipStream_t fs = b->side[2];
+            hipStream_t fs = b->fused_stream;
             HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
             HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
             hipEvent_t f0 = nullptr, f1 = nullptr;
@@ -1599,7 +1604,9 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     }
     // Cluster-resident march: the fused workgroups march all n_sub sub-timesteps in one launch per class (on a
     // side stream when other surfaces are streamed beside them); whatever is not fused is streamed as before.
-    const bool fused = b->any_fused && b->fusion_on && n_sub > 0;
+    // (a fused launch costs about as much as three streamed sub-timesteps before its first sub-timestep is done —
+    // measured, 1 M x 32: 341 / 198 / 113 us per sub-timestep at 1 / 2 / 5 per call against 171 streamed)
+    const bool fused = b->any_fused && b->fusion_on && n_sub >= kFusedMinSubsteps;
     bool streamed = !fused;
     if (fused) {
         for (int c = 0; c < kNumFast; c++) streamed = streamed || b->n_stream_tiles[c] > 0;
@@ -1608,8 +1615,8 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     hipStream_t fs = b->stream;
     if (fused) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (streamed && b->side[2] != nullptr) {
-            fs = b->side[2];
+        if (streamed && b->fused_stream != nullptr) {
+            fs = b->fused_stream;
             HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
             HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
         }

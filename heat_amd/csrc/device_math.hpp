@@ -93,7 +93,7 @@ __device__ __forceinline__ double zone_mcp(double volume, double temp) {
 }
 
 // nu_90 — reference src/gas.rs:285-307
-__device__ inline double nu_90(double ra, double a_gi, int &bad) {
+__device__ __attribute__((noinline)) double nu_90(double ra, double a_gi, int &bad) {
     double nu1;
     if (ra <= 1e4) {
         nu1 = 1. + 1.7596678 * 1e-10 * pow(ra, 2.2984755);
@@ -110,7 +110,7 @@ __device__ inline double nu_90(double ra, double a_gi, int &bad) {
 }
 
 // nu_60 — reference src/gas.rs:249-263
-__device__ inline double nu_60(double ra, double a_gi) {
+__device__ __attribute__((noinline)) double nu_60(double ra, double a_gi) {
     const double g = 0.5 / pow(1. + pow(ra / 3160., 20.6), 0.1);
     const double t = 0.0936 * pow(ra, 0.314) / (1. + g);
     const double t2 = t * t, t4 = t2 * t2;
@@ -121,7 +121,7 @@ __device__ inline double nu_60(double ra, double a_gi) {
 }
 
 // nusselt — reference src/gas.rs:197-315
-__device__ inline double nusselt(double ra, double gamma, double a_gi, int &bad) {
+__device__ __attribute__((noinline)) double nusselt(double ra, double gamma, double a_gi, int &bad) {
     const double THIRTY_RAD = 30. * kPi / 180.;
     const double EPSILON_RAD = 0.5 * kPi / 180.;
     gamma = fmod(gamma, kPi);

@@ -395,7 +395,9 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
     };
     auto conv = [&](double air_t, double forced, double nat_pos, double nat_neg, double fix, double surf_t) {
-        double hs = forced + tarp_natural_coef(air_t, surf_t, nat_pos, nat_neg, bad);  // convection.rs:165-167
+        double hs;
+        if (FUSED && (fa.pad & 8)) hs = forced + nat_pos * fabs(air_t - surf_t);  // (timing experiment: no cbrt)
+        else hs = forced + tarp_natural_coef(air_t, surf_t, nat_pos, nat_neg, bad);  // convection.rs:165-167
         if (hs != hs) bad |= FLAG_NAN_HS;                                // surface.rs:704-707
         if (fix == fix) hs = fix;
         return hs;

@@ -226,6 +226,7 @@ int32_t heat_batch_n_shared_zones(const heat_batch *b);
  * stay in registers, the zone balance is summed in LDS in the reference's order, and only the final temperatures,
  * coefficients and flows are written. Everything else is streamed one sub-timestep per launch beside it. Results are
  * the same as the streamed march's to the last bit of the zone sums' order (tested at 1e-9 against the oracle).
+ * March calls of fewer than three sub-timesteps are streamed as well (the fused launch only pays off from three on).
  * heat_batch_set_fusion(b, 0) streams everything (used to measure the per-sub-timestep kernel on its own). */
 int heat_batch_set_fusion(heat_batch *b, int32_t enabled);
 int64_t heat_batch_n_fused_surfaces(const heat_batch *b);

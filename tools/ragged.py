@@ -11,8 +11,9 @@ elif which == "glazing":
 else:
     md, st = mdl.uniform_massive(S, 32, dt=45.0)
 w = mdl.weather_series(20, 45.0)
-with HeatBatch(md) as b:
+nofuse = len(sys.argv) > 3 and sys.argv[3] == "nofuse"
+with HeatBatch(md, no_fusion=nofuse) as b:
     b.upload_state(st)
     b.march_resident(w); b.synchronize()
     b.set_timing(True); b.march_resident(w); b.synchronize()
-    print(which, b.class_counts(), b.get_timing())
+    print(which, "no_fusion" if nofuse else "", b.class_counts(), "fused", b.n_fused_surfaces, b.get_timing())
