@@ -480,7 +480,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     std::vector<BlockPlan> blocks;
     const bool fuse = !opt.no_fusion && !opt.force_general && !opt.no_palette;
     if (fuse && S > 0) {
-        auto fusable = [&](int64_t s) { return cat[s].kind == 0 && cat[s].pal && cat[s].ncav == 0; };
+        auto fusable = [&](int64_t s) { return cat[s].kind == 0 && cat[s].pal; };
         auto zone_of_side = [&](int64_t s, int side) -> int32_t {
             const int kind = side ? d->back_kind[s] : d->front_kind[s];
             return kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
@@ -537,10 +537,15 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         for (int64_t r = 0; r < Z; r++) {
             if (find((int32_t)r) != r || !cok[r] || coff[r + 1] == coff[r]) continue;
             // one blocking factor for the cluster: the cheapest that keeps every surface at two lanes or more
+            // (gas cavities: 4 or 8 nodes per lane only — the 16-node cavity variant does not fit the registers)
+            bool any_cav = false;
+            for (int64_t q = coff[r]; q < coff[r + 1]; q++) any_cav = any_cav || cat[csurf[q]].ncav > 0;
             int M = opt.nodes_per_lane;
+            if (M == 16 && any_cav) continue;  // streamed
             if (M == 0) {
                 double best = 0.0;
                 for (int m : ms_all) {
+                    if (m == 16 && any_cav) continue;
                     double c = 0.0;
                     bool ok = true;
                     for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
@@ -564,7 +569,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             }
             const int nz = (int)czones[r].size();
             if (!fits || tiles_needed(cnt) > kFusedMaxWaves || nz > kFusedMaxZones || ne > kFusedMaxEntries) continue;  // streamed
-            Category cc{0, nm, 0, 1};
+            Category cc{0, nm, any_cav ? 1 : 0, 1};
             const int cls = fast_class(M, cc);
             Open &o = open[cls];
             int merged[kWave + 1];
@@ -598,14 +603,15 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         for (int64_t s : lone) {
             Placed &pl = placed[s];
             int M = opt.nodes_per_lane;
+            const bool cav = cat[s].ncav > 0;
             if (M == 0) {
                 M = 4;
                 for (int m : {8, 16})
-                    if ((pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) < fused_cost(pl.n, M)) M = m;
+                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) < fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
-            if (k > kWave || k < 2) { lone_ok[s] = 0; continue; }
-            pl.cls = fast_class(M, Category{0, cat[s].nm, 0, 1});
+            if (k > kWave || k < 2 || (M == 16 && cav)) { lone_ok[s] = 0; continue; }
+            pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
             pl.k = k;
         }
         std::stable_sort(lone.begin(), lone.end(), [&](int64_t x, int64_t y) {
@@ -1161,7 +1167,7 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
             const int nb = (int)b->h_fblocks[c][g2].size();
             if (nb == 0) continue;
             fa.blocks = b->d_fblocks[c][g2].p;
-            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], g2 ? 8 : 4, nb, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
+            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 ? 8 : 4, nb, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
                                           b->na, b->sa, b->d_weather.p, b->d_flags.p,
                                           b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
         }

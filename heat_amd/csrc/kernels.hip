@@ -150,15 +150,15 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
 // temperatures never leave the registers, the zone balance (calculate_zones_abc + the analytic update,
 // model.rs:489-597,650-674) is summed from LDS in the same order and with the same arithmetic as k_zones, and
 // only the final temperatures, coefficients and flows are written back.
-// (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1 and CAV = 0: V and U are looked
-// up in the LDS palettes again every sub-timestep instead of being held in registers across the march.)
+// (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1; with cavities, M <= 8.)
 template <int M, int NM, int PAL, int CAV, int FUSED>
 __global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, FUSED ? 2 : 1)
 k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                 const double *__restrict__ zone_T, int *__restrict__ flags,
                 unsigned long long *__restrict__ nomass_iters, FusedArgs fa) {
-    static_assert(!FUSED || (PAL && !CAV), "the cluster-resident march exists for palette classes without cavities");
+    static_assert(!FUSED || (PAL && !(CAV && M == 16)),
+                  "the cluster-resident march exists for palette classes; with gas cavities for 4 or 8 nodes per lane");
     constexpr int kMaxW = FUSED ? FUSED : 4;
     constexpr int kLanes = kMaxW * kWave;
     // LDS: the palettes of the block's tiles; FUSED adds the per-side (hs, face temperature) pairs the zone
@@ -1272,7 +1272,7 @@ size_t fused_lds_bytes(int max_waves, int M) {
            4 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
 }
 
-template <int MM, int NN, int FW>
+template <int MM, int NN, int CC, int FW>
 static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                                    const SideArrays &sa, const StepWeather *weather, int *flags,
                                    unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
@@ -1280,29 +1280,31 @@ static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_ti
     static bool attr_set = false;  // (per instantiation) dynamic LDS above the 64 KB default needs the attribute
     if (!attr_set) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, 0, FW>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, CC, FW>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, 0, FW>), dim3(n_blocks), dim3(kWave * FW), lds, st, tiles, n_tiles, na,
-                       sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW>), dim3(n_blocks), dim3(kWave * FW), lds, st, tiles, n_tiles,
+                       na, sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
     return hipSuccess;
 }
 
-hipError_t launch_surfaces_fused(int M, int nm, int max_waves, int n_blocks, const FastTile *tiles, int n_tiles,
+hipError_t launch_surfaces_fused(int M, int nm, int cav, int max_waves, int n_blocks, const FastTile *tiles, int n_tiles,
                                  const NodeArrays &na, const SideArrays &sa, const StepWeather *weather, int *flags,
                                  unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
     if (n_blocks <= 0) return hipSuccess;
-#define HEAT_FUSED(MM, NN, FW) launch_fused_one<MM, NN, FW>(n_blocks, tiles, n_tiles, na, sa, weather, flags, nomass_iters, fa, st)
-#define HEAT_FUSED_M(MM)                                          \
-    (max_waves <= 4 ? (nm ? HEAT_FUSED(MM, 1, 4) : HEAT_FUSED(MM, 0, 4)) \
-                    : (nm ? HEAT_FUSED(MM, 1, 8) : HEAT_FUSED(MM, 0, 8)))
-    if (M == 4) return HEAT_FUSED_M(4);
-    if (M == 8) return HEAT_FUSED_M(8);
-    return HEAT_FUSED_M(16);
-#undef HEAT_FUSED_M
+    if (cav && M == 16) return hipErrorInvalidValue;  // (the planner never asks for it)
+#define HEAT_FUSED(MM, NN, CC, FW) \
+    launch_fused_one<MM, NN, CC, FW>(n_blocks, tiles, n_tiles, na, sa, weather, flags, nomass_iters, fa, st)
+#define HEAT_FUSED_NW(MM, CC)                                              \
+    (max_waves <= 4 ? (nm ? HEAT_FUSED(MM, 1, CC, 4) : HEAT_FUSED(MM, 0, CC, 4)) \
+                    : (nm ? HEAT_FUSED(MM, 1, CC, 8) : HEAT_FUSED(MM, 0, CC, 8)))
+    if (M == 4) return cav ? HEAT_FUSED_NW(4, 1) : HEAT_FUSED_NW(4, 0);
+    if (M == 8) return cav ? HEAT_FUSED_NW(8, 1) : HEAT_FUSED_NW(8, 0);
+    return HEAT_FUSED_NW(16, 0);
+#undef HEAT_FUSED_NW
 #undef HEAT_FUSED
 }
 

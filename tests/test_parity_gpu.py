@@ -507,3 +507,20 @@ def test_cluster_resident_march_config2_and_lone_surfaces(oracle):
     assert_state_close(md, ref, got)
     with HeatBatch(md) as b:
         assert b.n_fused_surfaces == 300
+
+
+def test_cluster_resident_march_with_gas_cavities(oracle):
+    # Trombe-like walls (massive / gas cavity / massive) in fused clusters: Cavity::u_value once per sub-timestep,
+    # inside the resident loop (4 or 8 nodes per lane)
+    md, st = mdl.glazing_cavity(480, Z=8, dt=45.0, seed=13, trombe_fraction=1.0)
+    w = mdl.weather_series(25, 45.0)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w)
+    assert iters == gpu_iters
+    assert_state_close(md, ref, got)
+    with HeatBatch(md) as b:
+        assert b.n_fused_surfaces == 480, (b.n_fused_surfaces, b.class_counts())
+    streamed = st.copy()
+    with HeatBatch(md, no_fusion=True) as b:
+        b.upload_state(streamed)
+        b.march(streamed, w)
+    assert np.allclose(got, streamed, rtol=1e-10, atol=1e-10)
