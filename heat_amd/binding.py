@@ -233,7 +233,7 @@ class HeatBatch:
     """Device-resident batch of surfaces + zones (≙ ThermalModel, src/model.rs:54-77)."""
 
     def __init__(self, md, device=-1, force_general=False, nodes_per_lane=0, use_graph=False, stream=None,
-                 n_ranks=1, rank=0, no_palette=False, no_fusion=False):
+                 n_ranks=1, rank=0, no_palette=False, no_fusion=False, fuse_always=False):
         self._L = load_library()
         self._h = _H()
         desc, keep = make_desc(md)
@@ -246,7 +246,7 @@ class HeatBatch:
         opt.n_ranks = n_ranks
         opt.rank = rank
         opt.no_palette = 1 if no_palette else 0
-        opt.no_fusion = 1 if no_fusion else 0
+        opt.no_fusion = 1 if no_fusion else (2 if fuse_always else 0)
         _check(self._L.heat_batch_create_ex(C.byref(desc), C.byref(opt), C.byref(self._h)))
         self.n_state = int(md["n_state"])
         self.n_zones = int(md["n_zones"])

@@ -158,8 +158,9 @@ struct heat_batch {
     int64_t n_fused_surfaces = 0;
     int n_stream_tiles[kNumFast] = {};  // tiles marched one sub-timestep per launch; the fused workgroups' tiles follow
     // cluster-resident march: workgroups per class, in two width groups (<= 4 tiles, <= 8 tiles)
-    std::vector<FusedBlock> h_fblocks[kNumFast][2];
-    DevBuf<FusedBlock> d_fblocks[kNumFast][2];
+    // workgroup lists per class: index = width group (0: <= 4 wavefronts, 1: <= 8) + 2 * mixed (small-surface tiles too)
+    std::vector<FusedBlock> h_fblocks[kNumFast][4];
+    DevBuf<FusedBlock> d_fblocks[kNumFast][4];
     DevBuf<int32_t> d_fzones, d_fzone_eoff;
     DevBuf<uint16_t> d_fslots;
     DevBuf<double> d_side_area;
@@ -168,7 +169,7 @@ struct heat_batch {
     // that owns a zone shared with another rank is demoted — its tiles and zones are streamed, so that the zone
     // exchange can happen every sub-timestep)
     std::vector<FastTile> h_tiles0[kNumFast];
-    std::vector<FusedBlock> h_fblocks0[kNumFast][2];
+    std::vector<FusedBlock> h_fblocks0[kNumFast][4];
     int n_stream_tiles0[kNumFast] = {};
     std::vector<int32_t> h_fzones;      // global zone of fused-zone index i (FusedBlock::first_zone + j)
     DevBuf<int32_t> d_zlist_stream;     // sharded: touched zones that no fused workgroup owns (shared ones first)
@@ -183,6 +184,9 @@ struct heat_batch {
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
     int n_small_tiles = 0;      // small tiles, cavity-free ones first
     int n_small_plain_tiles = 0;
+    int n_smallcav_stream_tiles = 0;  // streamed small-with-cavity tiles; the fused workgroups' small tiles follow them
+    int n_smallcav_stream_tiles0 = 0;
+    std::vector<GeneralTile> h_gen_tiles0;
     size_t nm_count_base[kNumFast + 1] = {};
     DevBuf<GeneralTile> d_gen_tiles;
     int64_t gen_base = 0;     // first node slot of the general group
@@ -476,11 +480,14 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     // fast-path wall without cavities and it fits kFusedMaxWaves tiles / kFusedMaxZones zones; its surfaces then
     // share one blocking factor (4 or 8: the 16-node variant does not fit the register file with the state that
     // lives across sub-timesteps). Surfaces that face no zone at all are clusters of one and are packed freely.
-    struct BlockPlan { int cls; std::vector<int32_t> zones; };
+    struct BlockPlan { int cls; bool mixed; std::vector<int32_t> zones; };  // mixed: holds small-surface tiles too
     std::vector<BlockPlan> blocks;
-    const bool fuse = !opt.no_fusion && !opt.force_general && !opt.no_palette;
+    // no_fusion: 0 = fuse the clusters the cost model below expects to gain, 1 = never, 2 = every cluster that can be
+    const bool fuse = opt.no_fusion != 1 && !opt.force_general && !opt.no_palette;
+    const bool fuse_always = opt.no_fusion == 2;
     if (fuse && S > 0) {
-        auto fusable = [&](int64_t s) { return cat[s].kind == 0 && cat[s].pal; };
+        auto is_small = [&](int64_t s) { return cat[s].kind == kSmall || cat[s].kind == kSmallCav; };
+        auto fusable = [&](int64_t s) { return (cat[s].kind == 0 && cat[s].pal) || is_small(s); };
         auto zone_of_side = [&](int64_t s, int side) -> int32_t {
             const int kind = side ? d->back_kind[s] : d->front_kind[s];
             return kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
@@ -521,12 +528,13 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         for (int64_t z = 0; z < Z; z++) czones[find((int32_t)z)].push_back((int32_t)z);
 
         // open workgroup per class: surfaces per k, zones so far
-        struct Open { int blk = -1; int cnt[kWave + 1] = {}; int nz = 0; int ne = 0; };
-        Open open[kNumFast];
-        auto new_block = [&](int cls) {
-            blocks.push_back(BlockPlan{cls, {}});
+        struct Open { int blk = -1; int cnt[kWave + 1] = {}; int nsmall = 0; int nz = 0; int ne = 0; };
+        Open open[2 * kNumFast];  // [class][mixed]
+        auto new_block = [&](int cls, bool mixed) {
+            blocks.push_back(BlockPlan{cls, mixed, {}});
             return (int)blocks.size() - 1;
         };
+        auto small_tiles = [](int n_small) { return (n_small + kWave - 1) / kWave; };
         // The cluster-resident kernels are bound by instruction issue, not by HBM: cost per padded node by
         // measured VALU instructions per node and sub-timestep (M = 16 : 8 : 4 = 0.76 : 1.11 : 1.9).
         auto fused_cost = [&](int n, int m) {
@@ -538,8 +546,16 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             if (find((int32_t)r) != r || !cok[r] || coff[r + 1] == coff[r]) continue;
             // one blocking factor for the cluster: the cheapest that keeps every surface at two lanes or more
             // (gas cavities: 4 or 8 nodes per lane only — the 16-node cavity variant does not fit the registers)
+            // Small all-no-mass surfaces (glazing, thin walls) of the cluster get wavefronts of their own in the
+            // workgroup (one lane per surface); such a "mixed" workgroup runs the universal kernel variant of its
+            // blocking factor: no-mass facings allowed, gas cavities allowed (up to 8 nodes per lane).
             bool any_cav = false;
-            for (int64_t q = coff[r]; q < coff[r + 1]; q++) any_cav = any_cav || cat[csurf[q]].ncav > 0;
+            int n_small = 0;
+            for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                if (is_small(csurf[q])) n_small++;
+                else any_cav = any_cav || cat[csurf[q]].ncav > 0;
+            }
+            const bool mixed = n_small > 0;
             int M = opt.nodes_per_lane;
             if (M == 16 && any_cav) continue;  // streamed
             if (M == 0) {
@@ -549,6 +565,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                     double c = 0.0;
                     bool ok = true;
                     for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                        if (is_small(csurf[q])) continue;
                         const int n = placed[csurf[q]].n;
                         ok = ok && (n + m - 1) / m >= 2;
                         c += fused_cost(n, m);
@@ -561,45 +578,64 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             bool fits = true;
             for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
                 const Placed &pl = placed[csurf[q]];
+                ne += (zone_of_side(csurf[q], 0) >= 0) + (zone_of_side(csurf[q], 1) >= 0);
+                if (is_small(csurf[q])) continue;
                 const int k = (pl.n + M - 1) / M;
                 if (k > kWave || k < 2) { fits = false; break; }  // (the fused kernels have no single-lane path)
                 cnt[k]++;
                 nm |= cat[csurf[q]].nm;
-                ne += (zone_of_side(csurf[q], 0) >= 0) + (zone_of_side(csurf[q], 1) >= 0);
             }
             const int nz = (int)czones[r].size();
-            if (!fits || tiles_needed(cnt) > kFusedMaxWaves || nz > kFusedMaxZones || ne > kFusedMaxEntries) continue;  // streamed
-            Category cc{0, nm, any_cav ? 1 : 0, 1};
+            if (!fits || tiles_needed(cnt) + small_tiles(n_small) > kFusedMaxWaves || nz > kFusedMaxZones ||
+                ne > kFusedMaxEntries)
+                continue;  // streamed
+            if (!fuse_always) {
+                // Cost model (measured, profiles/README.md): the resident march beats the streamed kernels only with
+                // 16 nodes per lane (2.1x on 1 M x 32; with 8 it is level, with 4 it loses), with well-filled
+                // wavefronts, and without glazing in the workgroup: a window's no-mass loop re-evaluates its gas
+                // cavity every pass (surface.rs:814) — a long serial chain the whole workgroup would wait for at
+                // every sub-timestep's barrier (rooms with double glazing: 8x slower fused than streamed).
+                int lanes = 0, n_cav_small = 0;
+                for (int k = 1; k <= kWave; k++) lanes += cnt[k] * k;
+                for (int64_t q = coff[r]; q < coff[r + 1]; q++) n_cav_small += cat[csurf[q]].kind == kSmallCav;
+                const int tiles = tiles_needed(cnt);
+                if (M != 16 || n_cav_small > 0 || tiles == 0 || lanes < 0.6 * kWave * tiles) continue;  // streamed
+            }
+            Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1};
             const int cls = fast_class(M, cc);
-            Open &o = open[cls];
+            Open &o = open[2 * cls + (mixed ? 1 : 0)];
             int merged[kWave + 1];
             for (int k = 0; k <= kWave; k++) merged[k] = o.cnt[k] + cnt[k];
             // Workgroups of four tiles are the target (two of them share a compute unit, so one's zone balance —
             // a short serial section — overlaps the other's stencil work): clusters are merged only up to four
             // tiles; a cluster that needs five to eight gets a workgroup of its own.
-            if (o.blk < 0 || tiles_needed(merged) > 4 || o.nz + nz > kFusedMaxZones ||
+            if (o.blk < 0 || tiles_needed(merged) + small_tiles(o.nsmall + n_small) > 4 || o.nz + nz > kFusedMaxZones ||
                 o.ne + ne > kFusedMaxEntries) {
                 o = Open();
-                o.blk = new_block(cls);
+                o.blk = new_block(cls, mixed);
                 for (int k = 0; k <= kWave; k++) merged[k] = cnt[k];
             }
             for (int k = 0; k <= kWave; k++) o.cnt[k] = merged[k];
+            o.nsmall += n_small;
             o.nz += nz;
             o.ne += ne;
             for (int32_t z : czones[r]) blocks[o.blk].zones.push_back(z);
             for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
                 Placed &pl = placed[csurf[q]];
-                pl.cls = cls;
-                pl.k = (pl.n + M - 1) / M;
                 pl.blk = o.blk;
+                if (is_small(csurf[q])) {
+                    pl.cls = kSmallCav;  // (one kind of small tile inside workgroups: the cavity variant covers both)
+                } else {
+                    pl.cls = cls;
+                    pl.k = (pl.n + M - 1) / M;
+                }
             }
         }
         // surfaces that face no zone: any grouping will do; workgroups of up to 4 tiles of equal k
-        for (int c = 0; c < kNumFast; c++) open[c] = Open();
         std::vector<int64_t> lone;
         std::vector<uint8_t> lone_ok(S, 1);
         for (int64_t s = 0; s < S; s++)
-            if (sroot[s] < 0 && fusable(s)) lone.push_back(s);
+            if (sroot[s] < 0 && fusable(s) && !is_small(s)) lone.push_back(s);
         for (int64_t s : lone) {
             Placed &pl = placed[s];
             int M = opt.nodes_per_lane;
@@ -610,7 +646,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                     if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) < fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
-            if (k > kWave || k < 2 || (M == 16 && cav)) { lone_ok[s] = 0; continue; }
+            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && M != 16)) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
             pl.k = k;
         }
@@ -626,7 +662,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 const int cap = 4 * (kWave / pl.k);
                 if (pl.cls != cur_cls || pl.k != cur_k || in_blk >= cap) {
                     cur_cls = pl.cls; cur_k = pl.k; in_blk = 0;
-                    cur_blk = new_block(pl.cls);
+                    cur_blk = new_block(pl.cls, false);
                 }
                 pl.blk = cur_blk;
                 in_blk++;
@@ -662,6 +698,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     size_t pos = 0;
     struct NodeMap { int64_t base; int Lk; int k; int M; int g; int tile; };  // per device surface
     std::vector<int> blk_first_tile(blocks.size(), -1), blk_n_tiles(blocks.size(), 0);
+    std::vector<int> blk_first_small(blocks.size(), -1), blk_n_small(blocks.size(), 0);
     std::vector<NodeMap> nmap(S);
     int prev_cls = -1;
     while (pos < (size_t)S) {
@@ -702,9 +739,16 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         } else {
             if (gen_tiles.empty()) b->gen_base = node_cursor;
             size_t end = pos;
-            while (end < (size_t)S && end < pos + (size_t)kWave && placed[order[end]].cls == p0.cls) end++;
+            while (end < (size_t)S && end < pos + (size_t)kWave && placed[order[end]].cls == p0.cls &&
+                   placed[order[end]].blk == p0.blk)
+                end++;
             if (p0.cls < kGeneral) b->n_small_tiles++;
             if (p0.cls == kSmall) b->n_small_plain_tiles++;
+            if (p0.cls == kSmallCav && p0.blk < 0) b->n_smallcav_stream_tiles++;
+            if (p0.blk >= 0) {
+                if (blk_first_small[p0.blk] < 0) blk_first_small[p0.blk] = (int)gen_tiles.size();
+                blk_n_small[p0.blk]++;
+            }
             int n_max = 0;
             for (size_t q = pos; q < end; q++) n_max = std::max(n_max, placed[order[q]].n);
             GeneralTile t;
@@ -719,7 +763,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 const int64_t s = order[q];
                 dev_of[s] = dcur;
                 orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos), 0};
+                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos), (int)gen_tiles.size() - 1};
                 dcur++;
             }
             node_cursor += (int64_t)n_max * kWave;
@@ -793,7 +837,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 if (!(placed[s].cls < kNumFast && kFastCAV[placed[s].cls])) continue;
                 const int64_t o = d->node_offset[s];
                 int r = 0;
-                for (int i = 0; i < placed[s].n && r < 2; i++)
+                for (int i = 0; i < placed[s].n && r < 2 && d->seg_cavity && d->n_cavities > 0; i++)
                     if (d->seg_cavity[o + i] >= 0) {
                         hCavRef[4 * dd + 2 * r] = i;
                         hCavRef[4 * dd + 2 * r + 1] = d->seg_cavity[o + i];
@@ -893,8 +937,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         std::vector<int> blk_fw(blocks.size(), 4);
         std::vector<int32_t> blk_first_zone(blocks.size(), 0);
         for (size_t bi = 0; bi < blocks.size(); bi++) {
-            if (blk_n_tiles[bi] <= 0) continue;  // (an empty plan: cannot happen, kept harmless)
-            blk_fw[bi] = blk_n_tiles[bi] <= 4 ? 4 : 8;
+            if (blk_n_tiles[bi] + blk_n_small[bi] <= 0) continue;  // (an empty plan: cannot happen, kept harmless)
+            blk_fw[bi] = blk_n_tiles[bi] + blk_n_small[bi] <= 4 ? 4 : 8;
             blk_first_zone[bi] = (int32_t)fz.size();
             for (size_t j = 0; j < blocks[bi].zones.size(); j++) {
                 const int32_t z = blocks[bi].zones[j];
@@ -927,15 +971,19 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 if (z < 0) continue;
                 const int bi = placed[s].blk;
                 const NodeMap &m = nmap[dev_of[s]];
-                const int lane = side ? (m.g * m.k + m.k - 1) : (m.g * m.k);
-                const uint32_t slot = (uint32_t)(side * kWave * blk_fw[bi] + (m.tile - blk_first_tile[bi]) * kWave + lane);
+                // fast-path surfaces: the first / last lane of the surface owns the side; small surfaces: their lane
+                const int lane = (m.M == 0) ? m.g : (side ? (m.g * m.k + m.k - 1) : (m.g * m.k));
+                const int wave_in_block = (m.M == 0) ? blk_n_tiles[bi] + (m.tile - blk_first_small[bi])
+                                                     : (m.tile - blk_first_tile[bi]);
+                const uint32_t slot = (uint32_t)(side * kWave * blk_fw[bi] + wave_in_block * kWave + lane);
                 fent[cur[fz_index[z]]++] = (uint16_t)slot;
                 side_lz[(int64_t)side * S + dev_of[s]] = (int16_t)lz_of_zone[z];
             }
         for (size_t bi = 0; bi < blocks.size(); bi++) {
-            if (blk_n_tiles[bi] <= 0) continue;
-            FusedBlock fb{blk_first_tile[bi], blk_n_tiles[bi], blk_first_zone[bi], (int32_t)blocks[bi].zones.size()};
-            b->h_fblocks[blocks[bi].cls][blk_fw[bi] == 4 ? 0 : 1].push_back(fb);
+            if (blk_n_tiles[bi] + blk_n_small[bi] <= 0) continue;
+            FusedBlock fb{std::max(blk_first_tile[bi], 0), blk_n_tiles[bi], blk_first_zone[bi],
+                          (int32_t)blocks[bi].zones.size(), std::max(blk_first_small[bi], 0), blk_n_small[bi]};
+            b->h_fblocks[blocks[bi].cls][(blk_fw[bi] == 4 ? 0 : 1) + (blocks[bi].mixed ? 2 : 0)].push_back(fb);
             b->any_fused = true;
         }
     }
@@ -945,9 +993,10 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         b->n_stream_zones = (int)sz.size();
         HIP_TRY(b->d_stream_zones.upload(sz));
     }
+    b->h_gen_tiles0 = gen_tiles;
+    b->n_smallcav_stream_tiles0 = b->n_smallcav_stream_tiles;
     for (int c = 0; c < kNumFast; c++) {
-        if (b->h_fblocks[c][0].empty() && b->h_fblocks[c][1].empty()) b->n_stream_tiles[c] = (int)fast_tiles[c].size();
-        for (int g2 = 0; g2 < 2; g2++) {
+        for (int g2 = 0; g2 < 4; g2++) {
             HIP_TRY(b->d_fblocks[c][g2].upload(b->h_fblocks[c][g2]));
             b->h_fblocks0[c][g2] = b->h_fblocks[c][g2];
         }
@@ -1075,8 +1124,10 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     // tail overlaps the next class's head.
     int n_launch = 0;
     for (int c = 0; c < kNumFast; c++) n_launch += nt[c] > 0;
+    // small tiles with cavities: the streamed ones come first, the fused workgroups' after them
+    const int n_cav_tiles = streamed_only ? b->n_smallcav_stream_tiles : b->n_small_tiles - b->n_small_plain_tiles;
     n_launch += b->n_small_plain_tiles > 0;
-    n_launch += b->n_small_tiles > b->n_small_plain_tiles;
+    n_launch += n_cav_tiles > 0;
     n_launch += b->n_gen_tiles > b->n_small_tiles;
     const bool fork = n_launch > 1 && b->side[0] != nullptr;
     int used = 0, slot = 0;
@@ -1115,8 +1166,8 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         launch_surfaces_small(0, b->d_gen_tiles.p, b->n_small_plain_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
                               b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p, cnt,
                               next_stream());
-    if (b->n_small_tiles > b->n_small_plain_tiles)
-        launch_surfaces_small(1, b->d_gen_tiles.p + b->n_small_plain_tiles, b->n_small_tiles - b->n_small_plain_tiles,
+    if (n_cav_tiles > 0)
+        launch_surfaces_small(1, b->d_gen_tiles.p + b->n_small_plain_tiles, n_cav_tiles,
                               b->na, b->gen_base, b->sa, b->d_cavs.p, b->d_weather.p, b->d_step.p, step_fixed,
                               b->d_zone_T.p, b->d_flags.p, cnt + (size_t)b->n_small_plain_tiles * kWave,
                               next_stream());
@@ -1162,12 +1213,15 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
     fa.n_sub = n_sub;
     static const int dbg = getenv("HEAT_AMD_FUSED_DEBUG") ? atoi(getenv("HEAT_AMD_FUSED_DEBUG")) : 0;
     fa.pad = dbg;  // timing experiments only (results are wrong with any bit set): 1 no zone math, 2 no zone sums, 4 no barriers
+    fa.gen_tiles = b->d_gen_tiles.p;
+    fa.gen_base = b->gen_base;
+    fa.small_iters = b->d_nomass_iters.p + b->nm_count_base[kNumFast];
     for (int c = 0; c < kNumFast; c++)
-        for (int g2 = 0; g2 < 2; g2++) {
+        for (int g2 = 0; g2 < 4; g2++) {
             const int nb = (int)b->h_fblocks[c][g2].size();
             if (nb == 0) continue;
             fa.blocks = b->d_fblocks[c][g2].p;
-            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 ? 8 : 4, nb, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
+            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 >> 1, (g2 & 1) ? 8 : 4, nb, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
                                           b->na, b->sa, b->d_weather.p, b->d_flags.p,
                                           b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
         }
@@ -1438,27 +1492,54 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
     b->any_fused = false;
     int64_t n_fused_now = 0;
     std::vector<uint8_t> zone_fused(b->n_zones, 0);
+    auto owns_shared_zone = [&](const FusedBlock &fb) {
+        for (int j = 0; j < fb.n_zones; j++)
+            if (slot[b->h_fzones[fb.first_zone + j]] >= 0) return true;
+        return false;
+    };
+    // small-surface tiles of the workgroups (general layout): [plain | streamed with cavities | DEMOTED | kept | catch-all]
+    std::vector<int32_t> new_first_small(b->h_gen_tiles0.size() + 1, 0);
+    {
+        const std::vector<GeneralTile> &g0 = b->h_gen_tiles0;
+        const int head = b->n_small_plain_tiles + b->n_smallcav_stream_tiles0;
+        std::vector<GeneralTile> g(g0.begin(), g0.begin() + head);
+        int n_demoted = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int c = 0; c < kNumFast; c++)
+                for (int g2 = 0; g2 < 4; g2++)
+                    for (const FusedBlock &fb : b->h_fblocks0[c][g2]) {
+                        if (fb.n_small <= 0 || (pass == 0) != owns_shared_zone(fb)) continue;
+                        new_first_small[fb.first_small] = (int32_t)g.size();
+                        g.insert(g.end(), g0.begin() + fb.first_small, g0.begin() + fb.first_small + fb.n_small);
+                        if (pass == 0) n_demoted += fb.n_small;
+                    }
+        g.insert(g.end(), g0.begin() + b->n_small_tiles, g0.end());
+        b->n_smallcav_stream_tiles = b->n_smallcav_stream_tiles0 + n_demoted;
+        HIP_TRY(b->d_gen_tiles.upload(g));
+    }
     for (int c = 0; c < kNumFast; c++) {
         const std::vector<FastTile> &t0 = b->h_tiles0[c];
-        if (b->h_fblocks0[c][0].empty() && b->h_fblocks0[c][1].empty()) continue;
+        bool any = false;
+        for (int g2 = 0; g2 < 4; g2++) any = any || !b->h_fblocks0[c][g2].empty();
+        if (!any) continue;
         std::vector<FastTile> t(t0.begin(), t0.begin() + b->n_stream_tiles0[c]);
-        std::vector<FusedBlock> keep[2];
+        std::vector<FusedBlock> keep[4];
         for (int pass = 0; pass < 2; pass++)          // pass 0: demoted blocks' tiles, pass 1: kept blocks' tiles
-            for (int g2 = 0; g2 < 2; g2++)
+            for (int g2 = 0; g2 < 4; g2++)
                 for (const FusedBlock &fb : b->h_fblocks0[c][g2]) {
-                    bool shared = false;
-                    for (int j = 0; j < fb.n_zones; j++) shared = shared || slot[b->h_fzones[fb.first_zone + j]] >= 0;
-                    if ((pass == 0) != shared) continue;
+                    if ((pass == 0) != owns_shared_zone(fb)) continue;
                     FusedBlock nb = fb;
                     nb.first_tile = (int32_t)t.size();
+                    if (fb.n_small > 0) nb.first_small = new_first_small[fb.first_small];
                     t.insert(t.end(), t0.begin() + fb.first_tile, t0.begin() + fb.first_tile + fb.n_tiles);
                     if (pass == 1) {
                         keep[g2].push_back(nb);
                         for (int j = 0; j < fb.n_zones; j++) zone_fused[b->h_fzones[fb.first_zone + j]] = 1;
+                        for (int q = 0; q < fb.n_small; q++) n_fused_now += b->h_gen_tiles0[fb.first_small + q].G;
                     }
                 }
         int n_kept_tiles = 0;
-        for (int g2 = 0; g2 < 2; g2++) {
+        for (int g2 = 0; g2 < 4; g2++) {
             for (const FusedBlock &fb : keep[g2]) {
                 n_kept_tiles += fb.n_tiles;
                 for (int q = 0; q < fb.n_tiles; q++) n_fused_now += t[fb.first_tile + q].G;

@@ -137,6 +137,296 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small all-no-mass surfaces (n <= 4: single-layer no-mass walls, double glazing with its gas
+// cavity): one lane per surface, the whole chunk (0, n) in registers. Same layout as the general
+// group, reference operation order (march_nomass, surface.rs:790-898), no FMA contraction.
+#pragma clang fp contract(off)
+constexpr int kSmallNodes = 4;
+
+// One sub-timestep of one small surface: calc_border_conditions, march_nomass on the chunk (0, nn), the
+// coefficients and flows with the new temperatures (model.rs:150-169). T is updated in place.
+template <int CAV>
+__device__ __forceinline__ void small_step(const SideConst &cf, const SideConst &cb, const SideDyn &df, const SideDyn &db,
+                                           const double *__restrict__ hs_fix, int d, int S, const StepWeather &w,
+                                           double t_front_b, double t_back_b, int nn, double (&T)[kSmallNodes],
+                                           const double (&Us)[kSmallNodes], const double (&sol)[kSmallNodes],
+                                           const int (&cav)[kSmallNodes], const CavityDev *__restrict__ cavs, int &bad,
+                                           unsigned int &iters, SideOut &of, SideOut &ob) {
+    constexpr int NS = kSmallNodes;
+    const int bk = cb.kind_n & 3;
+    auto last = [&](const double (&x)[NS]) {
+        double r = x[0];
+#pragma unroll
+        for (int j = 1; j < NS; j++) r = (j == nn - 1) ? x[j] : r;
+        return r;
+    };
+    const double T0 = T[0], Tn = last(T);
+    const bool quirk = (bk == KIND_AMBIENT);
+    double f_hs, f_rad, b_hs, b_rad;
+    const double f_surf = T0, b_surf = quirk ? T0 : Tn;
+    eval_side(cf, w, t_front_b, t_front_b, df.rad_t, f_surf, f_hs, f_rad, bad);
+    eval_side(cb, w, t_back_b, quirk ? t_front_b : t_back_b, db.rad_t, b_surf, b_hs, b_rad, bad);
+    if (f_hs != f_hs || b_hs != b_hs) bad |= FLAG_NAN_HS;
+    if (hs_fix != nullptr) {
+        const double ff = hs_fix[d], fb = hs_fix[S + d];
+        if (ff == ff) f_hs = ff;
+        if (fb == fb) b_hs = fb;
+    }
+    const double f_radhs = rad_hs(cf.emis, f_rad, f_surf);
+    const double b_radhs = rad_hs(cb.emis, b_rad, b_surf);
+
+    double old_err = 99999.;
+    int count = 0;
+    for (;;) {
+        // get_k_q for the chunk (0, nn) — discretization.rs:596-700
+        double lo[NS], dg[NS], up[NS], q[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) { lo[j] = 0.0; dg[j] = 0.0; up[j] = 0.0; q[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < NS - 1; j++) {
+            if (j < nn - 1) {
+                double u = Us[j];
+                if constexpr (CAV) {
+                    if (cav[j] >= 0) u = cavity_u_value(cavs[cav[j]], T[j], T[j + 1], bad);
+                }
+                dg[j] += -u;
+                dg[j + 1] = dg[j + 1] - u;
+                up[j] = up[j] + u;
+                lo[j + 1] = lo[j + 1] + u;
+            }
+        }
+        q[0] += t_front_b * f_hs + f_radhs * (f_rad - T[0]);
+        dg[0] += -f_hs;
+        const double bq = t_back_b * b_hs + b_radhs * (b_rad - last(T));
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            if (j == nn - 1) { q[j] += bq; dg[j] += -b_hs; }
+        }
+        iters++;
+#pragma unroll
+        for (int j = 0; j < NS; j++) q[j] = (q[j] + sol[j]) * -1.;  // surface.rs:828-832
+        // mut_n_diag_gaussian(q, 3)
+#pragma unroll
+        for (int j = 1; j < NS; j++) {
+            if (j < nn) {
+                const double f = lo[j] / dg[j - 1];
+                dg[j] -= f * up[j - 1];
+                q[j] -= f * q[j - 1];
+            }
+        }
+        double x[NS];
+#pragma unroll
+        for (int j = NS - 1; j >= 0; j--) {
+            if (j == nn - 1) x[j] = q[j] / dg[j];
+            else if (j < nn - 1) x[j] = (q[j] - up[j] * x[(j + 1) % NS]) / dg[j];
+            else x[j] = 0.0;
+        }
+        double err = 0.0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) if (j < nn) err += fabs(x[j] - T[j]);
+        if (err > old_err) break;                            // surface.rs:842-848
+        if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
+#pragma unroll
+        for (int j = 0; j < NS; j++) if (j < nn) T[j] = (T[j] + x[j]) * 0.5;
+        const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
+        if (err / (double)nn < tol) break;
+        old_err = err;
+        count++;
+    }
+
+    {   // outputs with the new surface temperatures (model.rs:150-169)
+        const double T0n = T[0], Tnn = last(T);
+        double fh, bh, r_;
+        eval_side(cf, w, t_front_b, t_front_b, df.rad_t, T0n, fh, r_, bad);
+        eval_side(cb, w, t_back_b, t_back_b, db.rad_t, quirk ? T0n : Tnn, bh, r_, bad);
+        if (fh != fh || bh != bh) bad |= FLAG_NAN_HS;
+        if (hs_fix != nullptr) {
+            const double ff = hs_fix[d], fb = hs_fix[S + d];
+            if (ff == ff) fh = ff;
+            if (fb == fb) bh = fb;
+        }
+        of.hs = fh; of.flow = (T0n - t_front_b) * fh;
+        ob.hs = bh; ob.flow = (Tnn - t_back_b) * bh;
+    }
+}
+
+// A small surface's constants and state, fetched once (the general layout: node j of lane l at node_base + j * 64 + l).
+template <int CAV>
+__device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, const NodeArrays &na, int64_t gen_base,
+                                           const SideDyn &df, const SideDyn &db, int nn, double (&T)[kSmallNodes],
+                                           double (&Us)[kSmallNodes], double (&sol)[kSmallNodes], int (&cav)[kSmallNodes]) {
+    const double *Tg = na.T + tile.node_base + lane;
+    const double *Ug = na.U + tile.node_base + lane;
+    const int64_t gofs = tile.node_base - gen_base + lane;
+#pragma unroll
+    for (int j = 0; j < kSmallNodes; j++) {
+        const bool v = j < nn;
+        T[j] = v ? Tg[(int64_t)j * kWave] : 0.0;
+        Us[j] = v ? Ug[(int64_t)j * kWave] : 0.0;
+        cav[j] = (CAV && v) ? na.cav[gofs + (int64_t)j * kWave] : -1;
+        // surface.rs:930-931
+        double sj = v ? na.alpha_f[gofs + (int64_t)j * kWave] * df.solar : 0.0;
+        sj += v ? na.alpha_b[gofs + (int64_t)j * kWave] * db.solar : 0.0;
+        sol[j] = sj;
+    }
+}
+
+template <int CAV>
+__global__ void __launch_bounds__(256)
+k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
+                 SideArrays sd, const CavityDev *__restrict__ cavs,
+                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                 const double *__restrict__ zone_T, int *__restrict__ flags,
+                 unsigned long long *__restrict__ nomass_iters) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+    const GeneralTile tile = tiles[wave];
+    if (lane >= tile.G) return;
+    const int d = tile.surf_base + lane;
+    const int S = sd.S;
+    const SideConst cf = sd.sc[d];
+    const SideConst cb = sd.sc[S + d];
+    const SideDyn df = sd.dyn[d];
+    const SideDyn db = sd.dyn[S + d];
+    const int nn = cf.kind_n >> 16;
+    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const StepWeather w = weather[step];
+    double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
+    int cav[kSmallNodes];
+    small_load<CAV>(tile, lane, na, gen_base, df, db, nn, T, Us, sol, cav);
+    int bad = 0;
+    unsigned int iters = 0;
+    SideOut of, ob;
+    small_step<CAV>(cf, cb, df, db, sd.hs_fix, d, S, w, boundary_temperature(cf, w, zone_T),
+                    boundary_temperature(cb, w, zone_T), nn, T, Us, sol, cav, cavs, bad, iters, of, ob);
+    double *Tg = na.T + tile.node_base + lane;
+#pragma unroll
+    for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
+    sd.out[d] = of;
+    sd.out[S + d] = ob;
+    if (bad) atomicOr(flags, bad);
+    nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// Cluster-resident march, pieces shared by the fast-path wavefronts and the small-surface wavefronts of a
+// workgroup (layout.hpp, FusedBlock). LDS after the palettes (and V): see k_surfaces_fast.
+struct FusedLds {
+    double2 *hT;            // (hs * area, face temperature) per side: [2][lanes]
+    double *zT, *za0, *zb0, *zvol;
+    int *zoff;
+    unsigned short *slots;
+};
+
+// The block's zone data -> LDS (every wavefront of the block takes part; ends with a barrier).
+__device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int n_threads) {
+    const int e_first = fa.zone_eoff[blk.first_zone];
+    if ((int)threadIdx.x <= blk.n_zones) l.zoff[threadIdx.x] = fa.zone_eoff[blk.first_zone + threadIdx.x] - e_first;
+    if ((int)threadIdx.x < blk.n_zones) {
+        const int z = fa.zones[blk.first_zone + threadIdx.x];
+        l.zT[threadIdx.x] = fa.zone_T[z];
+        l.za0[threadIdx.x] = fa.a0[z];
+        l.zb0[threadIdx.x] = fa.b0[z];
+        l.zvol[threadIdx.x] = fa.vol[z];
+    }
+    const int n_e = fa.zone_eoff[blk.first_zone + blk.n_zones] - e_first;
+    for (int e = threadIdx.x; e < n_e; e += n_threads) l.slots[e] = fa.slots[e_first + e];
+    __syncthreads();
+}
+
+// calculate_zones_abc + estimate_zones_future_temperatures for the block's zones, as k_zones does: the sides'
+// (hs A, T) pairs are in LDS; one wavefront per zone sums them in the reference's order (model.rs:562-585).
+__device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int wib,
+                                                 int n_waves, int lane, int &bad_all) {
+    if (!(fa.pad & 4)) __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int j = wib; j < blk.n_zones && !(fa.pad & 2); j += n_waves) {
+        const int e0 = l.zoff[j], e1 = l.zoff[j + 1];
+        double a = 0.0, b = 0.0;
+        for (int e = e0 + lane; e < e1; e += kWave) {
+            const double2 ht = l.hT[l.slots[e]];
+            a += ht.x * ht.y;
+            b += ht.x;
+        }
+        a = wave_sum_f64(a);
+        b = wave_sum_f64(b);
+        if (lane == 0 && !(fa.pad & 1)) {
+            a += l.za0[j];
+            b += l.zb0[j];
+            const double tc = l.zT[j];
+            const double cz = zone_mcp(l.zvol[j], tc);  // model.rs:549-552
+            double ft = tc;
+            if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * fa.dt / cz);  // model.rs:662-666
+            if (ft != ft) bad_all |= FLAG_NAN_ZONE;                                // model.rs:417-420
+            l.zT[j] = ft;
+        }
+    }
+    if (!(fa.pad & 4)) __syncthreads();
+}
+
+// A wavefront of small surfaces inside a fused workgroup: one lane per surface, everything in registers over
+// the march; same arithmetic as k_surfaces_small (small_step), zone temperatures from LDS.
+#pragma clang fp contract(off)
+__device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int lanes_per_side,
+                                 int wib, int n_waves, int lane, const NodeArrays &na, const SideArrays &sd,
+                                 const StepWeather *__restrict__ weather, int *__restrict__ flags) {
+    const int tile_index = blk.first_small + (wib - blk.n_tiles);
+    const GeneralTile tile = fa.gen_tiles[tile_index];
+    const bool active = lane < tile.G;
+    const int d = tile.surf_base + (active ? lane : 0);
+    const int S = sd.S;
+    const SideConst cf = sd.sc[d];
+    const SideConst cb = sd.sc[S + d];
+    const SideDyn df = sd.dyn[d];
+    const SideDyn db = sd.dyn[S + d];
+    const int nn = cf.kind_n >> 16;
+    const int lz_f = fa.side_lzone[d], lz_b = fa.side_lzone[S + d];
+    const double area = fa.side_area[d];
+    double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
+    int cav[kSmallNodes];
+    small_load<1>(tile, active ? lane : 0, na, fa.gen_base, df, db, nn, T, Us, sol, cav);
+    fused_block_init(blk, fa, l, n_waves * kWave);
+    int bad_all = 0;
+    unsigned int iters = 0;
+    SideOut of{0.0, 0.0}, ob{0.0, 0.0};
+    auto btemp = [&](const SideConst &c, int lz, const StepWeather &w) -> double {  // model.rs:79-96
+        const int kind = c.kind_n & 3;
+        if (kind == KIND_SPACE) return l.zT[lz];
+        if (kind == KIND_AMBIENT) return c.ambient;
+        return w.t_out;
+    };
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < fa.n_sub; it++) {
+        const StepWeather w = weather[it];
+        int bad = 0;
+        small_step<1>(cf, cb, df, db, sd.hs_fix, d, S, w, btemp(cf, lz_f, w), btemp(cb, lz_b, w), nn, T, Us, sol, cav,
+                      na.cavs, bad, iters, of, ob);
+        if (active) {
+            bad_all |= bad;
+            double Tl = T[0];
+#pragma unroll
+            for (int j = 1; j < kSmallNodes; j++) Tl = (j == nn - 1) ? T[j] : Tl;
+            if ((cf.kind_n & 3) == KIND_SPACE) l.hT[wib * kWave + lane] = make_double2(of.hs * area, T[0]);
+            if ((cb.kind_n & 3) == KIND_SPACE) l.hT[lanes_per_side + wib * kWave + lane] = make_double2(ob.hs * area, Tl);
+        }
+        fused_zone_phase(blk, fa, l, wib, n_waves, lane, bad_all);
+    }
+    if ((int)threadIdx.x < blk.n_zones) fa.zone_T[fa.zones[blk.first_zone + threadIdx.x]] = l.zT[threadIdx.x];
+    if (active) {
+        double *Tg = na.T + tile.node_base + lane;
+#pragma unroll
+        for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
+        sd.out[d] = of;
+        sd.out[S + d] = ob;
+        if (fa.small_iters) fa.small_iters[(int64_t)tile_index * kWave + lane] += iters;
+    }
+    if (bad_all) atomicOr(flags, bad_all);  // (lane 0 of a zone-owning wave may carry a zone flag while inactive)
+}
+#pragma clang fp contract(fast)
+
 // NM = 1: the surface may carry a no-mass FACING node (node 0 and/or node n-1, every other node
 // massive): each is a one-node no-mass chunk, solved by the reference's damped fixed-point loop
 // (march_nomass, surface.rs:790-898) in the face lane before the massive nodes march.
@@ -151,7 +441,8 @@ __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in
 // model.rs:489-597,650-674) is summed from LDS in the same order and with the same arithmetic as k_zones, and
 // only the final temperatures, coefficients and flows are written back.
 // (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1; with cavities, M <= 8.)
-template <int M, int NM, int PAL, int CAV, int FUSED>
+// SMALL = 1: the workgroup may also hold wavefronts of small all-no-mass surfaces (fused_small_wave).
+template <int M, int NM, int PAL, int CAV, int FUSED, int SMALL = 0>
 __global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, FUSED ? 2 : 1)
 k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
@@ -172,21 +463,32 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // zone [kFusedMaxZones + 1]; the slot lists.
     constexpr bool kVinLds = FUSED && M == 16;
     double *const s_V = s_dyn + kLanes * kPal;
-    double2 *const s_hT = reinterpret_cast<double2 *>(s_V + (kVinLds ? M : 0) * kLanes);
-    double *const s_zT = reinterpret_cast<double *>(s_hT) + 4 * kLanes;
-    double *const s_za0 = s_zT + kFusedMaxZones;
-    double *const s_zb0 = s_za0 + kFusedMaxZones;
-    double *const s_zvol = s_zb0 + kFusedMaxZones;
-    int *const s_zoff = reinterpret_cast<int *>(s_zvol + kFusedMaxZones);
-    unsigned short *const s_slots = reinterpret_cast<unsigned short *>(s_zoff + kFusedMaxZones + 2);
+    FusedLds fl;
+    fl.hT = reinterpret_cast<double2 *>(s_V + (kVinLds ? M : 0) * kLanes);
+    fl.zT = reinterpret_cast<double *>(fl.hT) + 4 * kLanes;
+    fl.za0 = fl.zT + kFusedMaxZones;
+    fl.zb0 = fl.za0 + kFusedMaxZones;
+    fl.zvol = fl.zb0 + kFusedMaxZones;
+    fl.zoff = reinterpret_cast<int *>(fl.zvol + kFusedMaxZones);
+    fl.slots = reinterpret_cast<unsigned short *>(fl.zoff + kFusedMaxZones + 2);
+    double2 *const s_hT = fl.hT;
+    double *const s_zT = fl.zT;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x >> 6;
     int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
     int n_waves = gridDim.x * (blockDim.x >> 6);
-    FusedBlock blk{0, 0, 0, 0};
+    FusedBlock blk{0, 0, 0, 0, 0, 0};
+    int blk_waves = 0;  // wavefronts of the workgroup that have work
     if constexpr (FUSED) {
         blk = fa.blocks[blockIdx.x];
-        if (wib >= blk.n_tiles) return;  // (before any barrier: a finished wave does not take part in s_barrier)
+        blk_waves = blk.n_tiles + (SMALL ? blk.n_small : 0);
+        if (wib >= blk_waves) return;  // (before any barrier: a finished wave does not take part in s_barrier)
+        if constexpr (SMALL) {
+            if (wib >= blk.n_tiles) {
+                fused_small_wave(blk, fa, fl, kLanes, wib, blk_waves, lane, na, sd, weather, flags);
+                return;
+            }
+        }
         wave0 = blk.first_tile + wib;
         n_waves = 1 << 30;
     }
@@ -286,20 +588,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
         }
     }
-    if constexpr (FUSED) {
-        const int e_first = fa.zone_eoff[blk.first_zone];
-        if (threadIdx.x <= blk.n_zones) s_zoff[threadIdx.x] = fa.zone_eoff[blk.first_zone + threadIdx.x] - e_first;
-        if (threadIdx.x < blk.n_zones) {
-            const int z = fa.zones[blk.first_zone + threadIdx.x];
-            s_zT[threadIdx.x] = fa.zone_T[z];
-            s_za0[threadIdx.x] = fa.a0[z];
-            s_zb0[threadIdx.x] = fa.b0[z];
-            s_zvol[threadIdx.x] = fa.vol[z];
-        }
-        const int n_e = fa.zone_eoff[blk.first_zone + blk.n_zones] - e_first;
-        for (int e = threadIdx.x; e < n_e; e += blk.n_tiles * kWave) s_slots[e] = fa.slots[e_first + e];
-        __syncthreads();  // the block's zone data are in LDS
-    }
+    if constexpr (FUSED) fused_block_init(blk, fa, fl, blk_waves * kWave);  // the block's zone data -> LDS
 
     const int first_lane = g * k;
     const int nn = kind_n_mine >> 16;
@@ -576,31 +865,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     bad_all |= bad;
 
     if constexpr (FUSED) {
-        // ---- zones of the block: calculate_zones_abc + estimate_zones_future_temperatures, as k_zones does ----
-        if (!(fa.pad & 4)) __syncthreads();
-#pragma clang loop unroll(disable)
-        for (int j = wib; j < blk.n_zones && !(fa.pad & 2); j += blk.n_tiles) {
-            const int e0 = s_zoff[j], e1 = s_zoff[j + 1];
-            double a = 0.0, b = 0.0;
-            for (int e = e0 + lane; e < e1; e += kWave) {  // model.rs:562-585
-                const double2 ht = s_hT[s_slots[e]];
-                a += ht.x * ht.y;
-                b += ht.x;
-            }
-            a = wave_sum_f64(a);
-            b = wave_sum_f64(b);
-            if (lane == 0 && !(fa.pad & 1)) {
-                a += s_za0[j];
-                b += s_zb0[j];
-                const double tc = s_zT[j];
-                const double cz = zone_mcp(s_zvol[j], tc);  // model.rs:549-552
-                double ft = tc;
-                if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * fa.dt / cz);  // model.rs:662-666
-                if (ft != ft) bad_all |= FLAG_NAN_ZONE;                                // model.rs:417-420
-                s_zT[j] = ft;
-            }
-        }
-        if (!(fa.pad & 4)) __syncthreads();
+        fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
 #pragma unroll
         for (int j = 0; j < M; j++) T[j] = aux[j];
     }
@@ -854,160 +1119,6 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
 }
 #pragma clang fp contract(fast)
 
-// ---------------------------------------------------------------------------
-// Small all-no-mass surfaces (n <= 4: single-layer no-mass walls, double glazing with its gas
-// cavity): one lane per surface, the whole chunk (0, n) in registers. Same layout as the general
-// group, reference operation order (march_nomass, surface.rs:790-898), no FMA contraction.
-#pragma clang fp contract(off)
-template <int CAV>
-__global__ void __launch_bounds__(256)
-k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
-                 SideArrays sd, const CavityDev *__restrict__ cavs,
-                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
-                 const double *__restrict__ zone_T, int *__restrict__ flags,
-                 unsigned long long *__restrict__ nomass_iters) {
-    constexpr int NS = 4;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= n_tiles) return;
-    const GeneralTile tile = tiles[wave];
-    if (lane >= tile.G) return;
-    const int d = tile.surf_base + lane;
-    const int S = sd.S;
-
-    const SideConst cf = sd.sc[d];
-    const SideConst cb = sd.sc[S + d];
-    const SideDyn df = sd.dyn[d];
-    const SideDyn db = sd.dyn[S + d];
-    const int nn = cf.kind_n >> 16;
-    const int bk = cb.kind_n & 3;
-    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
-    const StepWeather w = weather[step];
-
-    double *Tg = na.T + tile.node_base + lane;
-    const double *Ug = na.U + tile.node_base + lane;
-    const int64_t gofs = tile.node_base - gen_base + lane;
-    double T[NS], Us[NS], sol[NS];
-    int cav[NS];
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-        const bool v = j < nn;
-        T[j] = v ? Tg[(int64_t)j * kWave] : 0.0;
-        Us[j] = v ? Ug[(int64_t)j * kWave] : 0.0;
-        cav[j] = (CAV && v) ? na.cav[gofs + (int64_t)j * kWave] : -1;
-        // surface.rs:930-931
-        double sj = v ? na.alpha_f[gofs + (int64_t)j * kWave] * df.solar : 0.0;
-        sj += v ? na.alpha_b[gofs + (int64_t)j * kWave] * db.solar : 0.0;
-        sol[j] = sj;
-    }
-
-    int bad = 0;
-    const double t_front_b = boundary_temperature(cf, w, zone_T);
-    const double t_back_b = boundary_temperature(cb, w, zone_T);
-    auto last = [&](const double (&x)[NS]) {
-        double r = x[0];
-#pragma unroll
-        for (int j = 1; j < NS; j++) r = (j == nn - 1) ? x[j] : r;
-        return r;
-    };
-    const double T0 = T[0], Tn = last(T);
-    const bool quirk = (bk == KIND_AMBIENT);
-    double f_hs, f_rad, b_hs, b_rad;
-    const double f_surf = T0, b_surf = quirk ? T0 : Tn;
-    eval_side(cf, w, t_front_b, t_front_b, df.rad_t, f_surf, f_hs, f_rad, bad);
-    eval_side(cb, w, t_back_b, quirk ? t_front_b : t_back_b, db.rad_t, b_surf, b_hs, b_rad, bad);
-    if (f_hs != f_hs || b_hs != b_hs) bad |= FLAG_NAN_HS;
-    if (sd.hs_fix != nullptr) {
-        const double ff = sd.hs_fix[d], fb = sd.hs_fix[S + d];
-        if (ff == ff) f_hs = ff;
-        if (fb == fb) b_hs = fb;
-    }
-    const double f_radhs = rad_hs(cf.emis, f_rad, f_surf);
-    const double b_radhs = rad_hs(cb.emis, b_rad, b_surf);
-
-    unsigned int iters = 0;
-    double old_err = 99999.;
-    int count = 0;
-    for (;;) {
-        // get_k_q for the chunk (0, nn) — discretization.rs:596-700
-        double lo[NS], dg[NS], up[NS], q[NS];
-#pragma unroll
-        for (int j = 0; j < NS; j++) { lo[j] = 0.0; dg[j] = 0.0; up[j] = 0.0; q[j] = 0.0; }
-#pragma unroll
-        for (int j = 0; j < NS - 1; j++) {
-            if (j < nn - 1) {
-                double u = Us[j];
-                if constexpr (CAV) {
-                    if (cav[j] >= 0) u = cavity_u_value(cavs[cav[j]], T[j], T[j + 1], bad);
-                }
-                dg[j] += -u;
-                dg[j + 1] = dg[j + 1] - u;
-                up[j] = up[j] + u;
-                lo[j + 1] = lo[j + 1] + u;
-            }
-        }
-        q[0] += t_front_b * f_hs + f_radhs * (f_rad - T[0]);
-        dg[0] += -f_hs;
-        const double bq = t_back_b * b_hs + b_radhs * (b_rad - last(T));
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            if (j == nn - 1) { q[j] += bq; dg[j] += -b_hs; }
-        }
-        iters++;
-#pragma unroll
-        for (int j = 0; j < NS; j++) q[j] = (q[j] + sol[j]) * -1.;  // surface.rs:828-832
-        // mut_n_diag_gaussian(q, 3)
-#pragma unroll
-        for (int j = 1; j < NS; j++) {
-            if (j < nn) {
-                const double f = lo[j] / dg[j - 1];
-                dg[j] -= f * up[j - 1];
-                q[j] -= f * q[j - 1];
-            }
-        }
-        double x[NS];
-#pragma unroll
-        for (int j = NS - 1; j >= 0; j--) {
-            if (j == nn - 1) x[j] = q[j] / dg[j];
-            else if (j < nn - 1) x[j] = (q[j] - up[j] * x[(j + 1) % NS]) / dg[j];
-            else x[j] = 0.0;
-        }
-        double err = 0.0;
-#pragma unroll
-        for (int j = 0; j < NS; j++) if (j < nn) err += fabs(x[j] - T[j]);
-        if (err > old_err) break;                            // surface.rs:842-848
-        if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
-#pragma unroll
-        for (int j = 0; j < NS; j++) if (j < nn) T[j] = (T[j] + x[j]) * 0.5;
-        const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
-        if (err / (double)nn < tol) break;
-        old_err = err;
-        count++;
-    }
-#pragma unroll
-    for (int j = 0; j < NS; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
-
-    {   // outputs with the new surface temperatures (model.rs:150-169)
-        const double T0n = T[0], Tnn = last(T);
-        double fh, bh, r_;
-        eval_side(cf, w, t_front_b, t_front_b, df.rad_t, T0n, fh, r_, bad);
-        eval_side(cb, w, t_back_b, t_back_b, db.rad_t, quirk ? T0n : Tnn, bh, r_, bad);
-        if (fh != fh || bh != bh) bad |= FLAG_NAN_HS;
-        if (sd.hs_fix != nullptr) {
-            const double ff = sd.hs_fix[d], fb = sd.hs_fix[S + d];
-            if (ff == ff) fh = ff;
-            if (fb == fb) bh = fb;
-        }
-        SideOut of, ob;
-        of.hs = fh; of.flow = (T0n - t_front_b) * fh;
-        ob.hs = bh; ob.flow = (Tnn - t_back_b) * bh;
-        sd.out[d] = of;
-        sd.out[S + d] = ob;
-    }
-    if (bad) atomicOr(flags, bad);
-    nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
-}
-#pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------
 // Zones: one wavefront per zone.
@@ -1272,7 +1383,7 @@ size_t fused_lds_bytes(int max_waves, int M) {
            4 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
 }
 
-template <int MM, int NN, int CC, int FW>
+template <int MM, int NN, int CC, int FW, int SM>
 static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                                    const SideArrays &sa, const StepWeather *weather, int *flags,
                                    unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
@@ -1280,27 +1391,34 @@ static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_ti
     static bool attr_set = false;  // (per instantiation) dynamic LDS above the 64 KB default needs the attribute
     if (!attr_set) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, CC, FW>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, CC, FW, SM>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW>), dim3(n_blocks), dim3(kWave * FW), lds, st, tiles, n_tiles,
-                       na, sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW, SM>), dim3(n_blocks), dim3(kWave * FW), lds, st, tiles,
+                       n_tiles, na, sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
     return hipSuccess;
 }
 
-hipError_t launch_surfaces_fused(int M, int nm, int cav, int max_waves, int n_blocks, const FastTile *tiles, int n_tiles,
-                                 const NodeArrays &na, const SideArrays &sa, const StepWeather *weather, int *flags,
-                                 unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
+// mixed: the workgroups also hold small-surface wavefronts; those run one universal variant per blocking factor
+// (no-mass facings allowed, gas cavities allowed up to 8 nodes per lane).
+hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_waves, int n_blocks, const FastTile *tiles,
+                                 int n_tiles, const NodeArrays &na, const SideArrays &sa, const StepWeather *weather,
+                                 int *flags, unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
     if (n_blocks <= 0) return hipSuccess;
     if (cav && M == 16) return hipErrorInvalidValue;  // (the planner never asks for it)
-#define HEAT_FUSED(MM, NN, CC, FW) \
-    launch_fused_one<MM, NN, CC, FW>(n_blocks, tiles, n_tiles, na, sa, weather, flags, nomass_iters, fa, st)
-#define HEAT_FUSED_NW(MM, CC)                                              \
-    (max_waves <= 4 ? (nm ? HEAT_FUSED(MM, 1, CC, 4) : HEAT_FUSED(MM, 0, CC, 4)) \
-                    : (nm ? HEAT_FUSED(MM, 1, CC, 8) : HEAT_FUSED(MM, 0, CC, 8)))
+#define HEAT_FUSED(MM, NN, CC, FW, SM) \
+    launch_fused_one<MM, NN, CC, FW, SM>(n_blocks, tiles, n_tiles, na, sa, weather, flags, nomass_iters, fa, st)
+    if (mixed) {
+        if (M == 4) return max_waves <= 4 ? HEAT_FUSED(4, 1, 1, 4, 1) : HEAT_FUSED(4, 1, 1, 8, 1);
+        if (M == 8) return max_waves <= 4 ? HEAT_FUSED(8, 1, 1, 4, 1) : HEAT_FUSED(8, 1, 1, 8, 1);
+        return max_waves <= 4 ? HEAT_FUSED(16, 1, 0, 4, 1) : HEAT_FUSED(16, 1, 0, 8, 1);
+    }
+#define HEAT_FUSED_NW(MM, CC)                                                    \
+    (max_waves <= 4 ? (nm ? HEAT_FUSED(MM, 1, CC, 4, 0) : HEAT_FUSED(MM, 0, CC, 4, 0)) \
+                    : (nm ? HEAT_FUSED(MM, 1, CC, 8, 0) : HEAT_FUSED(MM, 0, CC, 8, 0)))
     if (M == 4) return cav ? HEAT_FUSED_NW(4, 1) : HEAT_FUSED_NW(4, 0);
     if (M == 8) return cav ? HEAT_FUSED_NW(8, 1) : HEAT_FUSED_NW(8, 0);
     return HEAT_FUSED_NW(16, 0);

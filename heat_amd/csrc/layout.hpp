@@ -133,6 +133,8 @@ struct FusedBlock {
     int32_t n_tiles;     // <= kFusedMaxWaves
     int32_t first_zone;  // into FusedArgs::zones / zone_eoff
     int32_t n_zones;     // <= kFusedMaxZones
+    int32_t first_small; // small all-no-mass surfaces of the block's clusters (glazing, thin walls): tiles of the general
+    int32_t n_small;     // layout, one wavefront each, after the fast-path wavefronts; n_tiles + n_small <= kFusedMaxWaves
 };
 // A contribution to a zone's heat balance (model.rs:562-585) is the LDS slot of the side that makes it:
 //   slot = side * (64 * W) + wave_in_block * 64 + lane of the side's owner   (W = 4 or 8, the block's width group)
@@ -149,6 +151,9 @@ struct FusedArgs {
     double dt;
     int32_t n_sub;              // sub-timesteps marched by one launch
     int32_t pad;
+    const GeneralTile *gen_tiles;        // workgroups with small surfaces
+    int64_t gen_base;
+    unsigned long long *small_iters;     // no-mass pass counters of the general-layout tiles ([tile][lane])
 };
 
 struct ZoneEntry {

@@ -341,6 +341,80 @@ def clustered_massive(S, Z=None, dt=45.0, seed=11, n_lo=8, n_hi=40, pair_fractio
     return md, state
 
 
+def rooms_with_windows(S, Z=None, dt=45.0, seed=23, n_lo=8, n_hi=32, window_fraction=0.2, thin_fraction=0.08):
+    """Rooms as real models have them: massive walls (some with no-mass facings) plus double-glazed windows
+    (4 no-mass nodes around a gas cavity, src/cavity.rs:79-88) and thin no-mass partitions (2 nodes), all facing
+    the room's zone; some walls and partitions separate the two zones of a pair. The clusters mix fast-path and
+    small surfaces (the "mixed" workgroups of the cluster-resident march)."""
+    rng = np.random.default_rng(seed)
+    Z = Z if Z is not None else max(2, S // 20)
+    md = empty(S, Z, dt)
+    r = rng.random(S)
+    glazing = r < window_fraction
+    thin = (r >= window_fraction) & (r < window_fraction + thin_fraction)
+    facing = (r >= window_fraction + thin_fraction) & (r < window_fraction + thin_fraction + 0.2)
+    n_nodes = rng.integers(n_lo, n_hi + 1, S).astype(np.int64)
+    n_nodes[glazing] = 4
+    n_nodes[thin] = 2
+    k, rho_cp, dx = _draw_materials(rng, S, dt)
+    off, surf, local, first, last, mass, u = _massive_nodes(n_nodes, k, rho_cp, dx)
+    # walls with no-mass facings (as in ragged_mixed)
+    u_ins = rng.uniform(0.5, 3.0, S)
+    fx = facing[surf]
+    second = local == 1
+    before_last = local == (n_nodes[surf] - 2)
+    m_el = (rho_cp * dx)[surf]
+    mass = np.where(fx & (first | last), 0.0, mass)
+    mass = np.where(fx & (second | before_last), m_el / 2., mass)
+    u = np.where(fx & first, u_ins[surf], u)
+    u = np.where(fx & before_last, u_ins[surf], u)
+    # thin no-mass partitions
+    tn = thin[surf]
+    mass = np.where(tn, 0.0, mass)
+    u = np.where(tn & first, rng.uniform(0.5, 5.0, S)[surf], u)
+    # double glazing
+    gz = glazing[surf]
+    mass = np.where(gz, 0.0, mass)
+    u = np.where(gz & ((local == 0) | (local == 2)), 1.0 / 0.003, u)
+    u = np.where(gz & ((local == 1) | (local == 3)), 0.0, u)
+    segc = np.full(off[-1], -1, dtype=np.int32)
+    g_idx = np.cumsum(glazing) - 1
+    sel = gz & (local == 1)
+    segc[sel] = g_idx[surf[sel]]
+    tilt = rng.choice([math.pi / 2, math.pi / 2, math.radians(73.0), math.radians(30.0)], S)
+    n_g = int(glazing.sum())
+    cav = np.zeros(n_g, dtype=CAVITY_DTYPE)
+    cav["thickness"], cav["height"], cav["angle"] = 0.0127, 1.0, tilt[glazing]
+    cav["eout"], cav["ein"], cav["gas"] = 0.84, 0.84, rng.integers(0, 4, n_g)
+    md["node_offset"], md["mass"], md["uvalue"] = off, mass, u
+    if n_g:
+        md["seg_cavity"], md["cavities"] = segc, cav
+    fa = np.zeros(off[-1]); ba = np.zeros(off[-1])
+    fa[first] = rng.uniform(0.1, 0.9, S)
+    ba[last] = rng.uniform(0.1, 0.9, S)
+    a_f = np.array([0.05, 0.05, 0.03, 0.03])
+    fa = np.where(gz, a_f[np.minimum(local, 3)], fa)
+    ba = np.where(gz, a_f[::-1][np.minimum(local, 3)], ba)
+    md["front_alpha"], md["back_alpha"] = fa, ba
+    _fill_common(md, rng, S, Z, "outdoor_space")
+    md["cos_tilt"] = np.where(glazing, np.cos(tilt), md["cos_tilt"])
+    rr = rng.random(S)
+    zone_of = md["back_zone"].copy()
+    fk = md["front_kind"]
+    pair = (rr < 0.12) & ~glazing                # interior walls / partitions between the two zones of a pair
+    fk[pair] = SPACE
+    md["front_zone"] = np.where(pair, np.minimum(zone_of ^ 1, Z - 1), zone_of).astype(np.int32)
+    light = facing | thin | glazing
+    md["front_emissivity"] = np.where(light, md["front_emissivity"] * (0.2 / 0.9), md["front_emissivity"])
+    md["back_emissivity"] = np.where(light, md["back_emissivity"] * (0.2 / 0.9), md["back_emissivity"])
+    state = layout_state(md)
+    perturb_initial_temperatures(md, state, rng)
+    state[md["solar_front_slot"]] = rng.uniform(0, 800., S)
+    state[md["solar_back_slot"]] = np.where(glazing, rng.uniform(0, 100., S), 0.0)
+    set_ir_from_air(md, state, 10.0)
+    return md, state
+
+
 def perturb_initial_temperatures(md, state, rng):
     """Spreads the initial temperatures (the reference's all-22.0 start makes every natural
     convection coefficient hit its 0.1 floor, convection.rs:22,91-92)."""

@@ -145,7 +145,8 @@ typedef struct heat_batch_options {
     int32_t n_ranks;
     int32_t rank;
     int32_t no_palette;      /* 1: keep dt/mass and U as per-node arrays even where a palette would do */
-    int32_t no_fusion;       /* 1: never plan the cluster-resident march (see heat_batch_set_fusion) */
+    int32_t no_fusion;       /* cluster-resident march (see heat_batch_set_fusion): 0 = plan it for the clusters the cost
+                              * model expects to gain, 1 = never, 2 = for every cluster that structurally can (tests) */
 } heat_batch_options;
 
 /* ≙ ThermalModel::new + allocate_memory: validates, packs and uploads the constants. */

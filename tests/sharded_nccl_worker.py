@@ -84,14 +84,19 @@ def shared_zones_beside_a_fused_march():
     """Sharded batch whose clusters are fusable: the workgroups that own a shared zone are demoted to the streamed
     exchange loop (kernel -> ncclAllGather -> kernel every sub-timestep), the others march cluster-resident beside
     it on a side stream."""
-    md, st = mdl.clustered_massive(1200, Z=48, dt=45.0, seed=3)
+    for gen in (mdl.clustered_massive, mdl.rooms_with_windows):
+        _shared_zones_beside_a_fused_march(gen)
+
+
+def _shared_zones_beside_a_fused_march(gen):
+    md, st = gen(1200, Z=48, dt=45.0, seed=3)
     w = mdl.weather_series(11, 45.0)
     a0 = np.linspace(0., 30., 48)
     b0 = np.linspace(0., 1., 48)
     ref = st.copy()
     rc, iters = orc.OracleModel(md).march(ref, w, a0, b0)
     assert rc == 0
-    sm = ShardedMarch(md, 0, 1, device_index=0, collective="native", force_shared=[3, 20, 21, 47])
+    sm = ShardedMarch(md, 0, 1, device_index=0, collective="native", force_shared=[3, 20, 21, 47], fuse_always=True)
     assert sm.n_shared_zones == 4 and sm.batch.n_fused_surfaces > 0
     got = st.copy()
     sm.batch.upload_state(got)

@@ -466,7 +466,7 @@ def test_cluster_resident_march_matches_the_oracle_and_the_streamed_march(oracle
     rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
     assert rc == 0
     got = st.copy()
-    with HeatBatch(md, nodes_per_lane=npl) as b:
+    with HeatBatch(md, nodes_per_lane=npl, fuse_always=True) as b:
         nf = b.n_fused_surfaces
         assert 0 < nf < md["n_surfaces"]          # both kinds of clusters are present
         b.upload_state(got)
@@ -483,7 +483,7 @@ def test_cluster_resident_march_matches_the_oracle_and_the_streamed_march(oracle
     assert np.allclose(got, streamed, rtol=1e-11, atol=1e-11)
     # switched off at run time: the same layout, everything streamed
     off = st.copy()
-    with HeatBatch(md, nodes_per_lane=npl, use_graph=True) as b:
+    with HeatBatch(md, nodes_per_lane=npl, use_graph=True, fuse_always=True) as b:
         b.set_fusion(False)
         b.upload_state(off)
         b.march(off, w, a0, b0)
@@ -503,9 +503,9 @@ def test_cluster_resident_march_config2_and_lone_surfaces(oracle):
     md["front_kind"][::3] = mdl.AMBIENT
     md["front_ambient"][::3] = 17.5
     w = mdl.weather_series(30, 45.0)
-    ref, got, _, _, counts = run_both(oracle, md, st, w)
+    ref, got, _, _, counts = run_both(oracle, md, st, w, fuse_always=True)
     assert_state_close(md, ref, got)
-    with HeatBatch(md) as b:
+    with HeatBatch(md, fuse_always=True) as b:
         assert b.n_fused_surfaces == 300
 
 
@@ -514,13 +514,44 @@ def test_cluster_resident_march_with_gas_cavities(oracle):
     # inside the resident loop (4 or 8 nodes per lane)
     md, st = mdl.glazing_cavity(480, Z=8, dt=45.0, seed=13, trombe_fraction=1.0)
     w = mdl.weather_series(25, 45.0)
-    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, fuse_always=True)
     assert iters == gpu_iters
     assert_state_close(md, ref, got)
-    with HeatBatch(md) as b:
+    with HeatBatch(md, fuse_always=True) as b:
         assert b.n_fused_surfaces == 480, (b.n_fused_surfaces, b.class_counts())
     streamed = st.copy()
     with HeatBatch(md, no_fusion=True) as b:
         b.upload_state(streamed)
         b.march(streamed, w)
+    assert np.allclose(got, streamed, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("npl", [0, 4, 8, 16])
+def test_cluster_resident_march_of_rooms_with_windows(oracle, npl):
+    """Mixed workgroups: the walls of a room on fast-path wavefronts, its double-glazed windows and thin no-mass
+    partitions on small-surface wavefronts of the same workgroup (one lane per surface, small_step), one zone balance.
+    (fuse_always: the planner's cost model would stream rooms with double glazing — the machinery is tested here.)"""
+    md, st = mdl.rooms_with_windows(1400, Z=70, dt=45.0, seed=23 + npl)
+    w = mdl.weather_series(17, 45.0, wind_speed=2.5, wind_deg=75.0)
+    a0 = np.linspace(0., 80., 70)
+    b0 = np.linspace(0., 1.5, 70)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    got = st.copy()
+    with HeatBatch(md, nodes_per_lane=npl, fuse_always=True) as b:
+        counts = b.class_counts()
+        assert counts[3] > 0                       # windows / thin partitions are there ...
+        # ... and most rooms march cluster-resident, windows included (a forced blocking factor of 8 or 16 nodes per
+        # lane leaves the rooms with short walls — one lane per wall — to the streamed kernels)
+        assert b.n_fused_surfaces > (700 if npl in (0, 4) else -1)
+        b.upload_state(got)
+        b.march(got, w[:8], a0, b0)
+        b.march(got, w[8:], a0, b0)
+        assert b.nomass_iterations() == iters
+    assert_state_close(md, ref, got)
+    streamed = st.copy()
+    with HeatBatch(md, nodes_per_lane=npl, no_fusion=True) as b:
+        b.upload_state(streamed)
+        b.march(streamed, w, a0, b0)
     assert np.allclose(got, streamed, rtol=1e-10, atol=1e-10)

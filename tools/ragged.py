@@ -6,6 +6,10 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 which = sys.argv[2] if len(sys.argv) > 2 else "ragged"
 if which == "ragged":
     md, st = mdl.ragged_mixed(S, dt=45.0)
+elif which == "rooms":
+    md, st = mdl.rooms_with_windows(S, dt=45.0)
+elif which == "clustered":
+    md, st = mdl.clustered_massive(S, dt=45.0)
 elif which == "glazing":
     md, st = mdl.glazing_cavity(S, dt=45.0)
 else:
