@@ -677,13 +677,32 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     }
 
     // ---- order: class, then streamed surfaces before the fused workgroups, then lanes per surface ----
+    // Small surfaces with a gas cavity are grouped by the branch of the Nusselt correlation their tilt selects
+    // (gas.rs:197-315: five ranges of the cavity angle): the lanes of a wavefront then take the same branch instead of
+    // the wavefront running all of them one after the other.
+    std::vector<uint8_t> tilt_key(S, 0);
+    if (d->seg_cavity && d->n_cavities > 0)
+        for (int64_t s = 0; s < S; s++) {
+            if (placed[s].cls != kSmallCav && !(placed[s].cls < kNumFast && kFastCAV[placed[s].cls])) continue;
+            const int64_t o = d->node_offset[s];
+            for (int i = 0; i < placed[s].n; i++)
+                if (d->seg_cavity[o + i] >= 0) {
+                    double g = std::fmod(d->cavities[d->seg_cavity[o + i]].angle, 3.14159265358979323846);
+                    if (g > 1.5707963267948966) g = 3.14159265358979323846 - g;  // the kernel flips the angle by the sign of dT
+                    const double deg = g * (180.0 / 3.14159265358979323846);
+                    tilt_key[s] = deg < 59.5 ? 0 : (deg < 60.5 ? 1 : (deg < 89.5 ? 2 : 3));
+                    break;
+                }
+        }
     std::vector<int64_t> order(S);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
         const Placed &a = placed[x], &c = placed[y];
         if (a.cls != c.cls) return a.cls < c.cls;
         if (a.blk != c.blk) return a.blk < c.blk;
-        if (a.cls < kNumFast) return a.k < c.k;
+        if (a.cls < kNumFast && a.k != c.k) return a.k < c.k;
+        if (tilt_key[x] != tilt_key[y]) return tilt_key[x] < tilt_key[y];
+        if (a.cls < kNumFast) return false;
         return a.n < c.n;
     });
 
