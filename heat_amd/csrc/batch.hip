@@ -120,7 +120,7 @@ struct DevBuf {
 };
 
 constexpr int kMaxNodesGeneral = 4096;
-constexpr int kFusedMinSubsteps = 3;  // march calls of fewer sub-timesteps are streamed
+constexpr int kFusedMinSubsteps = 3;  // march calls of fewer sub-timesteps are streamed (large batches)
 constexpr int kScratchArrays = 7;
 // fast classes: index = mi * 6 + nm * 3 + v;  M = 4 << mi;  nm: no-mass facings allowed;
 // v = 0 per-node arrays, 1 palette constants, 2 palette + gas cavities between massive nodes
@@ -599,7 +599,11 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 for (int k = 1; k <= kWave; k++) lanes += cnt[k] * k;
                 for (int64_t q = coff[r]; q < coff[r + 1]; q++) n_cav_small += cat[csurf[q]].kind == kSmallCav;
                 const int tiles = tiles_needed(cnt);
-                if (M != 16 || n_cav_small > 0 || tiles == 0 || lanes < 0.6 * kWave * tiles) continue;  // streamed
+                // A small batch is bound by launches and latency, not by throughput: there the resident march wins
+                // with any blocking factor (one launch per march call instead of two or more per sub-timestep).
+                const bool small_batch = S <= 8192;
+                if (n_cav_small > 0 || tiles == 0) continue;                                        // streamed
+                if (!small_batch && (M != 16 || lanes < 0.6 * kWave * tiles)) continue;             // streamed
             }
             Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1};
             const int cls = fast_class(M, cc);
@@ -646,7 +650,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                     if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) < fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
-            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && M != 16)) { lone_ok[s] = 0; continue; }
+            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && M != 16 && S > 8192)) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
             pl.k = k;
         }
@@ -1663,7 +1667,8 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         // The clusters that own no shared zone march beside the exchange loop, in one launch per class on a side
         // stream: only the few surfaces around the shared zones go through kernel -> all-gather -> kernel every
         // sub-timestep, and that chain is shorter than the fused march it runs next to.
-        const bool fused = b->any_fused && b->fusion_on && n_sub >= kFusedMinSubsteps && b->fused_stream != nullptr;
+        const bool fused = b->any_fused && b->fusion_on && n_sub >= (b->n_surf <= 8192 ? 1 : kFusedMinSubsteps) &&
+                           b->fused_stream != nullptr;
         if (fused) {
             hipStream_t fs = b->fused_stream;
             HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
@@ -1712,7 +1717,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     // side stream when other surfaces are streamed beside them); whatever is not fused is streamed as before.
     // (a fused launch costs about as much as three streamed sub-timesteps before its first sub-timestep is done —
     // measured, 1 M x 32: 341 / 198 / 113 us per sub-timestep at 1 / 2 / 5 per call against 171 streamed)
-    const bool fused = b->any_fused && b->fusion_on && n_sub >= kFusedMinSubsteps;
+    const bool fused = b->any_fused && b->fusion_on && n_sub >= (b->n_surf <= 8192 ? 1 : kFusedMinSubsteps);
     bool streamed = !fused;
     if (fused) {
         for (int c = 0; c < kNumFast; c++) streamed = streamed || b->n_stream_tiles[c] > 0;
