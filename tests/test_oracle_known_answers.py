@@ -366,3 +366,26 @@ def test_nan_temperature_is_reported(oracle):
     state[md["first_node_slot"][0]] = np.nan
     rc, _ = oracle.OracleModel(md).iterate_surfaces(state, 0., 0., 10.)
     assert rc > 0
+
+
+@pytest.mark.parametrize("gen", ["clustered_massive", "rooms_with_windows"])
+def test_synthetic_cluster_workloads_are_well_posed(oracle, gen):
+    """The workloads the cluster-resident march is tested on (heat_amd/modeldict.py): the oracle marches them without
+    numerical failure, temperatures stay in a physical range, and the zone graph has the intended structure (small
+    clusters: pairs of zones; some surfaces face no zone at all)."""
+    from heat_amd import modeldict as mdl
+    md, st = getattr(mdl, gen)(400, Z=20, dt=45.0, seed=4)
+    w = mdl.weather_series(30, 45.0)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w)
+    assert rc == 0 and iters > 0
+    nodes = ref[mdl.node_slots(md)]
+    assert np.all(np.isfinite(ref)) and nodes.min() > -30. and nodes.max() < 120.
+    fz = np.where(md["front_kind"] == mdl.SPACE, md["front_zone"], -1)
+    bz = np.where(md["back_kind"] == mdl.SPACE, md["back_zone"], -1)
+    both = (fz >= 0) & (bz >= 0) & (fz != bz)
+    assert both.any() and np.all((fz[both] ^ 1) == bz[both])        # Space/Space walls join the two zones of a pair
+    if gen == "clustered_massive":
+        assert np.any((fz < 0) & (bz < 0))                           # walls that face no zone
+    else:
+        assert len(md["cavities"]) > 0 and np.any(np.diff(md["node_offset"]) == 2)   # windows and thin partitions
