@@ -151,7 +151,7 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
                                            const double *__restrict__ hs_fix, int d, int S, const StepWeather &w,
                                            double t_front_b, double t_back_b, int nn, double (&T)[kSmallNodes],
                                            const double (&Us)[kSmallNodes], const double (&sol)[kSmallNodes],
-                                           const int (&cav)[kSmallNodes], const CavityDev *__restrict__ cavs, int &bad,
+                                           const int (&cav)[kSmallNodes], const CavityDev (&cv)[kSmallNodes - 1], int &bad,
                                            unsigned int &iters, SideOut &of, SideOut &ob) {
     constexpr int NS = kSmallNodes;
     const int bk = cb.kind_n & 3;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
             if (j < nn - 1) {
                 double u = Us[j];
                 if constexpr (CAV) {
-                    if (cav[j] >= 0) u = cavity_u_value(cavs[cav[j]], T[j], T[j + 1], bad);
+                    if (cav[j] >= 0) u = cavity_u_value(cv[j], T[j], T[j + 1], bad);
                 }
                 dg[j] += -u;
                 dg[j + 1] = dg[j + 1] - u;
@@ -255,7 +255,8 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
 template <int CAV>
 __device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, const NodeArrays &na, int64_t gen_base,
                                            const SideDyn &df, const SideDyn &db, int nn, double (&T)[kSmallNodes],
-                                           double (&Us)[kSmallNodes], double (&sol)[kSmallNodes], int (&cav)[kSmallNodes]) {
+                                           double (&Us)[kSmallNodes], double (&sol)[kSmallNodes], int (&cav)[kSmallNodes],
+                                           CavityDev (&cv)[kSmallNodes - 1]) {
     const double *Tg = na.T + tile.node_base + lane;
     const double *Ug = na.U + tile.node_base + lane;
     const int64_t gofs = tile.node_base - gen_base + lane;
@@ -269,6 +270,14 @@ __device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, co
         double sj = v ? na.alpha_f[gofs + (int64_t)j * kWave] * df.solar : 0.0;
         sj += v ? na.alpha_b[gofs + (int64_t)j * kWave] * db.solar : 0.0;
         sol[j] = sj;
+    }
+    // the cavity records, once (the no-mass loop evaluates Cavity::u_value every pass: surface.rs:814)
+#pragma unroll
+    for (int j = 0; j < kSmallNodes - 1; j++) {
+        cv[j] = CavityDev{0., 0., 0., 0., 0., 0, 0};
+        if constexpr (CAV) {
+            if (cav[j] >= 0) cv[j] = na.cavs[cav[j]];
+        }
     }
 }
 
@@ -295,12 +304,13 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
     const StepWeather w = weather[step];
     double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
     int cav[kSmallNodes];
-    small_load<CAV>(tile, lane, na, gen_base, df, db, nn, T, Us, sol, cav);
+    CavityDev cv[kSmallNodes - 1];
+    small_load<CAV>(tile, lane, na, gen_base, df, db, nn, T, Us, sol, cav, cv);
     int bad = 0;
     unsigned int iters = 0;
     SideOut of, ob;
     small_step<CAV>(cf, cb, df, db, sd.hs_fix, d, S, w, boundary_temperature(cf, w, zone_T),
-                    boundary_temperature(cb, w, zone_T), nn, T, Us, sol, cav, cavs, bad, iters, of, ob);
+                    boundary_temperature(cb, w, zone_T), nn, T, Us, sol, cav, cv, bad, iters, of, ob);
     double *Tg = na.T + tile.node_base + lane;
 #pragma unroll
     for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
@@ -387,7 +397,8 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
     const double area = fa.side_area[d];
     double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
     int cav[kSmallNodes];
-    small_load<1>(tile, active ? lane : 0, na, fa.gen_base, df, db, nn, T, Us, sol, cav);
+    CavityDev cv[kSmallNodes - 1];
+    small_load<1>(tile, active ? lane : 0, na, fa.gen_base, df, db, nn, T, Us, sol, cav, cv);
     fused_block_init(blk, fa, l, n_waves * kWave);
     int bad_all = 0;
     unsigned int iters = 0;
@@ -403,7 +414,7 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
         const StepWeather w = weather[it];
         int bad = 0;
         small_step<1>(cf, cb, df, db, sd.hs_fix, d, S, w, btemp(cf, lz_f, w), btemp(cb, lz_b, w), nn, T, Us, sol, cav,
-                      na.cavs, bad, iters, of, ob);
+                      cv, bad, iters, of, ob);
         if (active) {
             bad_all |= bad;
             double Tl = T[0];
