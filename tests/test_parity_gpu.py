@@ -29,6 +29,16 @@ def run_both(oracle, md, state0, weather, a0=None, b0=None, **opts):
         b.march(got, weather, a0, b0)
         counts = b.class_counts()
         gpu_iters = b.nomass_iterations()
+        n_fused = b.n_fused_surfaces
+    if n_fused > 0 and "no_fusion" not in opts:
+        # the planner sent (part of) this batch through the cluster-resident march: the streamed kernels of the
+        # same batch are held to the same oracle
+        streamed = state0.copy()
+        with HeatBatch(md, **dict(opts, no_fusion=True, fuse_always=False)) as b:
+            b.upload_state(streamed)
+            b.march(streamed, weather, a0, b0)
+            assert b.nomass_iterations() == iters
+        assert_state_close(md, ref, streamed)
     return ref, got, iters, gpu_iters, counts
 
 
@@ -555,3 +565,38 @@ def test_cluster_resident_march_of_rooms_with_windows(oracle, npl):
         b.upload_state(streamed)
         b.march(streamed, w, a0, b0)
     assert np.allclose(got, streamed, rtol=1e-10, atol=1e-10)
+
+
+def test_headline_at_full_size(oracle):
+    """BASELINE's headline size (1 000 000 walls x 32 nodes, 10 000 zones) through properties that do not need the
+    oracle at that size: the cluster-resident march and the streamed march — different kernels, different data
+    paths — agree to 1e-10 on every owned slot after 23 sub-timesteps; 300 walls (three whole zones, so their zone
+    balance is complete) are checked against the oracle marching that sub-model alone; a second batch gives the same
+    bits (run-to-run determinism)."""
+    S, n, Z = 1_000_000, 32, 10_000
+    md, st = mdl.uniform_massive(S, n, Z=Z, dt=45.0)
+    w = mdl.weather_series(23, 45.0)
+    outs = []
+    for kw in (dict(), dict(no_fusion=True), dict()):
+        got = st.copy()
+        with HeatBatch(md, **kw) as b:
+            assert (b.n_fused_surfaces == S) == ("no_fusion" not in kw)
+            b.upload_state(got)
+            b.march_resident(w[:20])
+            b.march_resident(w[20:])
+            b.synchronize()
+            b.download_state(got)
+        outs.append(got)
+    assert np.all(np.isfinite(outs[0]))
+    assert np.allclose(outs[0], outs[1], rtol=1e-10, atol=1e-10)
+    assert np.array_equal(outs[0], outs[2])
+    # three whole zones against the oracle (uniform_massive: 100 consecutive walls per zone, front Outdoor / back Space)
+    idx = np.arange(4200, 4500)
+    assert set(md["back_zone"][idx]) == {42, 43, 44} and np.all(md["front_kind"][idx] == mdl.OUTDOOR)
+    sub = mdl.subset(md, idx)
+    ref = st.copy()
+    rc, _ = oracle.OracleModel(sub).march(ref, w)
+    assert rc == 0
+    for name, sl in (("nodes", mdl.node_slots(sub)), ("hs", sub["hs_back_slot"]), ("flow", sub["flow_front_slot"]),
+                     ("zones", md["zone_slot"][42:45])):
+        assert np.allclose(outs[0][sl], ref[sl], rtol=RTOL, atol=ATOL), name
