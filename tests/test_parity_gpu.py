@@ -600,3 +600,26 @@ def test_headline_at_full_size(oracle):
     for name, sl in (("nodes", mdl.node_slots(sub)), ("hs", sub["hs_back_slot"]), ("flow", sub["flow_front_slot"]),
                      ("zones", md["zone_slot"][42:45])):
         assert np.allclose(outs[0][sl], ref[sl], rtol=RTOL, atol=ATOL), name
+
+
+def test_config3_at_full_size_fast_kernels_equal_the_catch_all_kernel():
+    """BASELINE config 3 at its full size (1 000 000 ragged mixed surfaces, 8-64 nodes): the lane-blocked fast kernels
+    (+ the small-surface kernel) and the catch-all kernel — one lane per surface, tri-diagonal matrices in scratch, the
+    reference's operation order — are independent implementations of the same path; they agree on every owned slot
+    and on the number of passes of the no-mass loop."""
+    md, st = mdl.ragged_mixed(1_000_000, dt=45.0)
+    w = mdl.weather_series(6, 45.0)
+    res = []
+    for kw in (dict(), dict(force_general=True)):
+        got = st.copy()
+        with HeatBatch(md, **kw) as b:
+            counts = b.class_counts()
+            assert (counts[4] == 1_000_000) == ("force_general" in kw)
+            b.upload_state(got)
+            b.march_resident(w)
+            b.synchronize()
+            b.download_state(got)
+            res.append((got, b.nomass_iterations()))
+    assert res[0][1] == res[1][1] > 0
+    assert np.all(np.isfinite(res[0][0]))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-10, atol=1e-10)
