@@ -161,6 +161,7 @@ struct heat_batch {
     // workgroup lists per class: index = width group (0: <= 4 wavefronts, 1: <= 8) + 2 * mixed (small-surface tiles too)
     std::vector<FusedBlock> h_fblocks[kNumFast][4];
     DevBuf<FusedBlock> d_fblocks[kNumFast][4];
+    DevBuf<unsigned int> d_fqueue;      // work-queue counters of the fused launches (sharded batches): one per list
     DevBuf<int32_t> d_fzones, d_fzone_eoff;
     DevBuf<uint16_t> d_fslots;
     DevBuf<double> d_side_area;
@@ -1239,12 +1240,38 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
     fa.gen_tiles = b->d_gen_tiles.p;
     fa.gen_base = b->gen_base;
     fa.small_iters = b->d_nomass_iters.p + b->nm_count_base[kNumFast];
+    // Beside an exchange loop (sharded batch with shared zones) the fused launch must not take every wavefront slot
+    // of the chip: the loop's small kernels and the collective would each wait tens of microseconds for a slot
+    // (measured: 27-74 us instead of 5) and become the critical path. So the launch holds a few workgroups fewer
+    // than the chip has room for, and its workgroups take their FusedBlocks from a queue.
+    static const int reserve_env = getenv("HEAT_AMD_FUSED_RESERVE") ? atoi(getenv("HEAT_AMD_FUSED_RESERVE")) : -1;
+    const bool beside_exchange = (b->comm != nullptr && b->shared_set && b->n_shared > 0) || reserve_env >= 0;
+    static const int n_cu = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    if (beside_exchange && b->d_fqueue.n == 0) HIP_TRY(b->d_fqueue.zeros(kNumFast * 4));
     for (int c = 0; c < kNumFast; c++)
         for (int g2 = 0; g2 < 4; g2++) {
             const int nb = (int)b->h_fblocks[c][g2].size();
             if (nb == 0) continue;
             fa.blocks = b->d_fblocks[c][g2].p;
-            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 >> 1, (g2 & 1) ? 8 : 4, nb, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
+            fa.n_blocks = nb;
+            fa.queue = nullptr;
+            int grid = nb;
+            if (beside_exchange) {
+                const int fw = (g2 & 1) ? 8 : 4;
+                const int room = n_cu * fused_blocks_per_cu(kFastM[c], kFastCAV[c], g2 >> 1, fw);
+                const int reserve = reserve_env >= 0 ? reserve_env : (fw == 4 ? 16 : 8);
+                if (nb > room - reserve) {
+                    grid = std::max(1, room - reserve);
+                    fa.queue = b->d_fqueue.p + c * 4 + g2;
+                    HIP_TRY(hipMemsetAsync(fa.queue, 0, sizeof(unsigned int), st));
+                }
+            }
+            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 >> 1, (g2 & 1) ? 8 : 4, grid, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
                                           b->na, b->sa, b->d_weather.p, b->d_flags.p,
                                           b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
         }

@@ -103,7 +103,7 @@ __device__ __forceinline__ double from_next_lane(double v) { return dpp_rotate_f
 //   STAGE 0: in = T        acc = T + k/6     out = T + k/2
 //   STAGE 1: in = out      acc += k/3        out = T + k/2
 //   STAGE 2: in = out      acc += k/3        out = T + k
-//   STAGE 3: in = out                        out = acc + k/6   (the new temperatures)
+//   STAGE 3: in = out                        T   = acc + k/6   (the new temperatures, written over T: dead by then)
 // FULL: every surface of the tile fills its last lane (n == k M), so the last node is j == M-1.
 template <int M, bool FULL, int STAGE, typename VF>
 __device__ __forceinline__ void rk_stage(const double (&T)[M], const double (&in)[M], double (&out)[M],
@@ -490,24 +490,37 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     int n_waves = gridDim.x * (blockDim.x >> 6);
     FusedBlock blk{0, 0, 0, 0, 0, 0};
     int blk_waves = 0;  // wavefronts of the workgroup that have work
-    if constexpr (FUSED) {
-        blk = fa.blocks[blockIdx.x];
-        blk_waves = blk.n_tiles + (SMALL ? blk.n_small : 0);
-        if (wib >= blk_waves) return;  // (before any barrier: a finished wave does not take part in s_barrier)
-        if constexpr (SMALL) {
-            if (wib >= blk.n_tiles) {
-                fused_small_wave(blk, fa, fl, kLanes, wib, blk_waves, lane, na, sd, weather, flags);
-                return;
-            }
-        }
-        wave0 = blk.first_tile + wib;
-        n_waves = 1 << 30;
-    }
+    int bi = blockIdx.x;  // FUSED: the FusedBlock this workgroup marches
+    __shared__ int s_next_block;
     const int n_it = FUSED ? fa.n_sub : 1;
     const int step0 = FUSED ? 0 : ((step_fixed >= 0) ? step_fixed : *step_ptr);
     // Streaming (FUSED = 0), persistent waves: each walks the tile list with a grid stride, so the write-back of
     // one tile (a wave cannot retire before its stores are acknowledged) overlaps the loads of the next.
-    for (int wave = wave0; wave < n_tiles; wave += n_waves) {
+    // FUSED: one pass per FusedBlock; with a work queue (sharded batches, fa.queue) the workgroup takes further ones.
+    for (int wave = wave0; FUSED ? (bi < fa.n_blocks) : (wave < n_tiles); wave += n_waves) {
+    if constexpr (FUSED) {
+        blk = fa.blocks[bi];
+        blk_waves = blk.n_tiles + (SMALL ? blk.n_small : 0);
+        if (wib >= blk_waves) {
+            // no tile for this wavefront. One FusedBlock per workgroup: done (a finished wave does not take part in
+            // s_barrier). With the queue it has to stay for the next block, and keeps step with the barriers.
+            if (fa.queue == nullptr) return;
+            __syncthreads();
+            for (int it = 0; it < fa.n_sub; it++) {
+                if (!(fa.pad & 4)) { __syncthreads(); __syncthreads(); }
+            }
+            goto next_block;
+        }
+        if constexpr (SMALL) {
+            if (wib >= blk.n_tiles) {
+                fused_small_wave(blk, fa, fl, kLanes, wib, blk_waves, lane, na, sd, weather, flags);
+                if (fa.queue == nullptr) return;
+                goto next_block;
+            }
+        }
+        wave = blk.first_tile + wib;
+    }
+    {   // (a scope of its own: the jumps above pass over its declarations)
     const FastTile tile = tiles[wave];
     const int k = tile.k & 0xff;
     const bool full = (tile.k & 0x100) != 0;
@@ -834,12 +847,12 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         rk_stage<M, true, 0>(T, T, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
         rk_stage<M, true, 1>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
         rk_stage<M, true, 2>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, true, 3>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, true, 3>(T, aux, T, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     } else {
         rk_stage<M, false, 0>(T, T, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
         rk_stage<M, false, 1>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
         rk_stage<M, false, 2>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
-        rk_stage<M, false, 3>(T, aux, aux, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
+        rk_stage<M, false, 3>(T, aux, T, acc, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB, lane);
     }
 
     // ---- write back node temperatures (model.rs:145-147); FUSED: after the last sub-timestep only ----
@@ -847,18 +860,18 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         if (active) {
             double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
 #pragma unroll
-            for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(aux[2 * jp], aux[2 * jp + 1]);
+            for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(T[2 * jp], T[2 * jp + 1]);
         }
     }
 
     // ---- convection coefficients with the NEW temperatures + heat flows (model.rs:150-169) ----
-    const double T0n = wave_quirk ? shfl_f64(aux[0], first_lane) : aux[0];
-    const double Tln = pick_last(aux);
+    const double T0n = wave_quirk ? shfl_f64(T[0], first_lane) : T[0];
+    const double Tln = pick_last(T);
     const double Tnn = Tln;
     {
         const double surf_t = (my_back && !my_useF) ? Tnn : T0n;
         const double hs = conv(my_air, my_forced, c.cos_eff, c.alpha, my_fix, surf_t);
-        const double face_t = my_back ? Tln : aux[0];
+        const double face_t = my_back ? Tln : T[0];
         o_hs = hs;
         o_flow = (face_t - my_air) * hs;
         if constexpr (FUSED) {
@@ -875,18 +888,14 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     }
     bad_all |= bad;
 
-    if constexpr (FUSED) {
-        fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
-#pragma unroll
-        for (int j = 0; j < M; j++) T[j] = aux[j];
-    }
+    if constexpr (FUSED) fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
     }  // sub-timesteps
 
     if constexpr (FUSED) {
         if (active) {
             double2 *pT = reinterpret_cast<double2 *>(na.T + tile.node_base);
 #pragma unroll
-            for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(aux[2 * jp], aux[2 * jp + 1]);
+            for (int jp = 0; jp < M / 2; jp++) pT[jp * Lk + lane] = make_double2(T[2 * jp], T[2 * jp + 1]);
         }
         if (threadIdx.x < blk.n_zones) fa.zone_T[fa.zones[blk.first_zone + threadIdx.x]] = s_zT[threadIdx.x];
     }
@@ -910,7 +919,16 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
         if (lane == 0 && tot) nomass_iters[wave] += tot;
     }
-    }  // tile loop
+    }  // (tile scope)
+next_block:
+    if constexpr (FUSED) {
+        if (fa.queue == nullptr) break;
+        __syncthreads();  // every wavefront is done with this block's LDS
+        if (threadIdx.x == 0) s_next_block = (int)(gridDim.x + atomicAdd(fa.queue, 1u));
+        __syncthreads();
+        bi = s_next_block;
+    }
+    }  // tile / block loop
 }
 
 // ---------------------------------------------------------------------------
@@ -1395,7 +1413,7 @@ size_t fused_lds_bytes(int max_waves, int M) {
 }
 
 template <int MM, int NN, int CC, int FW, int SM>
-static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
+static hipError_t launch_fused_one(int grid_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                                    const SideArrays &sa, const StepWeather *weather, int *flags,
                                    unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
     const size_t lds = fused_lds_bytes(FW, MM);
@@ -1408,16 +1426,27 @@ static hipError_t launch_fused_one(int n_blocks, const FastTile *tiles, int n_ti
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW, SM>), dim3(n_blocks), dim3(kWave * FW), lds, st, tiles,
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW, SM>), dim3(grid_blocks), dim3(kWave * FW), lds, st, tiles,
                        n_tiles, na, sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
     return hipSuccess;
 }
 
 // mixed: the workgroups also hold small-surface wavefronts; those run one universal variant per blocking factor
 // (no-mass facings allowed, gas cavities allowed up to 8 nodes per lane).
-hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_waves, int n_blocks, const FastTile *tiles,
+// How many workgroups of a fused variant one compute unit holds (two waves per SIMD by registers; three for the
+// plain 4-node variants), also bounded by LDS.
+int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves) {
+    const int waves_per_simd = (M == 4 && !cav && !mixed) ? 3 : 2;
+    const int by_regs = std::max(1, waves_per_simd * 4 / max_waves);
+    const int by_lds = std::max<int>(1, (int)(160 * 1024 / fused_lds_bytes(max_waves, M)));
+    return std::min(by_regs, by_lds);
+}
+
+// grid_blocks workgroups for fa.n_blocks FusedBlocks: equal (fa.queue == nullptr) or fewer, with the work queue.
+hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_waves, int grid_blocks, const FastTile *tiles,
                                  int n_tiles, const NodeArrays &na, const SideArrays &sa, const StepWeather *weather,
                                  int *flags, unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
+    const int n_blocks = grid_blocks;
     if (n_blocks <= 0) return hipSuccess;
     if (cav && M == 16) return hipErrorInvalidValue;  // (the planner never asks for it)
 #define HEAT_FUSED(MM, NN, CC, FW, SM) \

@@ -151,6 +151,11 @@ struct FusedArgs {
     double dt;
     int32_t n_sub;              // sub-timesteps marched by one launch
     int32_t pad;
+    // Work queue (sharded batches): the launch holds fewer workgroups than blocks; a workgroup that has finished
+    // its cluster set takes the next one: gridDim.x + atomicAdd(queue, 1). nullptr: one workgroup per FusedBlock.
+    unsigned int *queue;
+    int32_t n_blocks;
+    int32_t pad2;
     const GeneralTile *gen_tiles;        // workgroups with small surfaces
     int64_t gen_base;
     unsigned long long *small_iters;     // no-mass pass counters of the general-layout tiles ([tile][lane])
