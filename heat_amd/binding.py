@@ -104,6 +104,7 @@ SYMBOLS = [
     ("heat_batch_n_shared_zones", C.c_int32, [_H]),
     ("heat_batch_set_fusion", C.c_int, [_H, C.c_int32]),
     ("heat_batch_n_fused_surfaces", C.c_int64, [_H]),
+    ("heat_batch_n_fused_launches", C.c_int64, [_H]),
     ("heat_batch_n_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_nodes", C.c_int64, [_H]),
     ("heat_batch_n_zones", C.c_int64, [_H]),
@@ -350,6 +351,10 @@ class HeatBatch:
     @property
     def n_fused_surfaces(self):
         return int(self._L.heat_batch_n_fused_surfaces(self._h))
+
+    @property
+    def n_fused_launches(self):
+        return int(self._L.heat_batch_n_fused_launches(self._h))
 
     def set_timing(self, enabled):
         _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))

@@ -250,6 +250,7 @@ struct heat_batch {
     std::vector<EvTriple> ev_triples;
     std::vector<EvPair> ev_fused_pairs;
     bool fusion_on = true;     // heat_batch_options::no_fusion / heat_batch_set_fusion
+    int64_t n_fused_launches = 0;  // cluster-resident launches issued since creation (introspection)
     bool graph_fused = false;  // what the captured sub-timestep graph leaves out
 
     ~heat_batch() {
@@ -1263,7 +1264,8 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
             int grid = nb;
             if (beside_exchange) {
                 const int fw = (g2 & 1) ? 8 : 4;
-                const int room = n_cu * fused_blocks_per_cu(kFastM[c], kFastCAV[c], g2 >> 1, fw);
+                static const int room_env = getenv("HEAT_AMD_FUSED_ROOM") ? atoi(getenv("HEAT_AMD_FUSED_ROOM")) : 0;  // tests
+                const int room = room_env > 0 ? room_env : n_cu * fused_blocks_per_cu(kFastM[c], kFastCAV[c], g2 >> 1, fw);
                 const int reserve = reserve_env >= 0 ? reserve_env : (fw == 4 ? 16 : 8);
                 if (nb > room - reserve) {
                     grid = std::max(1, room - reserve);
@@ -1271,6 +1273,11 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
                     HIP_TRY(hipMemsetAsync(fa.queue, 0, sizeof(unsigned int), st));
                 }
             }
+            static const bool trace = getenv("HEAT_AMD_TRACE") != nullptr;
+            if (trace)
+                fprintf(stderr, "heat_amd: fused launch%s: %d workgroups for %d blocks (class %d, list %d, %d sub-timesteps)\n",
+                        fa.queue ? " on the work queue" : "", grid, nb, c, g2, n_sub);
+            b->n_fused_launches++;
             HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 >> 1, (g2 & 1) ? 8 : 4, grid, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
                                           b->na, b->sa, b->d_weather.p, b->d_flags.p,
                                           b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
@@ -1330,7 +1337,7 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
     b->n_ranks = opt.n_ranks;
     b->rank = opt.rank;
     b->use_graph = opt.use_graph != 0;
-    b->fusion_on = opt.no_fusion == 0;
+    b->fusion_on = opt.no_fusion != 1;
     rc = select_device(b);
     if (!rc) {
         if (opt.stream) {
@@ -1899,5 +1906,6 @@ int heat_batch_set_fusion(heat_batch *b, int32_t enabled) {
 }
 
 int64_t heat_batch_n_fused_surfaces(const heat_batch *b) { return b ? b->n_fused_surfaces : 0; }
+int64_t heat_batch_n_fused_launches(const heat_batch *b) { return b ? b->n_fused_launches : 0; }
 
 }  // extern "C"

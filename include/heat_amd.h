@@ -231,6 +231,7 @@ int32_t heat_batch_n_shared_zones(const heat_batch *b);
  * heat_batch_set_fusion(b, 0) streams everything (used to measure the per-sub-timestep kernel on its own). */
 int heat_batch_set_fusion(heat_batch *b, int32_t enabled);
 int64_t heat_batch_n_fused_surfaces(const heat_batch *b);
+int64_t heat_batch_n_fused_launches(const heat_batch *b); /* cluster-resident launches issued since creation */
 
 /* Introspection (tests, bench). */
 int64_t heat_batch_n_surfaces(const heat_batch *b);

@@ -23,6 +23,15 @@ def main():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if "queue" in sys.argv:
+        # HEAT_AMD_FUSED_ROOM=20 (set by the caller): the fused launches beside the exchange loop hold 4 workgroups
+        # and take their FusedBlocks from the work queue (as a full-size sharded batch does with 496 of 10 000)
+        assert os.environ.get("HEAT_AMD_FUSED_ROOM") == "20"
+        for gen in (mdl.clustered_massive, mdl.rooms_with_windows):
+            _shared_zones_beside_a_fused_march(gen, S=6000, Z=240, shared=[3, 20, 21, 100, 239])
+        dist.destroy_process_group()
+        print("SHARDED OK")
+        return
     md, st = mdl.ragged_mixed(800, Z=8, dt=45.0, seed=21)
     w = mdl.weather_series(8, 45.0)
     ref = st.copy()
@@ -88,25 +97,27 @@ def shared_zones_beside_a_fused_march():
         _shared_zones_beside_a_fused_march(gen)
 
 
-def _shared_zones_beside_a_fused_march(gen):
-    md, st = gen(1200, Z=48, dt=45.0, seed=3)
+def _shared_zones_beside_a_fused_march(gen, S=1200, Z=48, shared=(3, 20, 21, 47)):
+    md, st = gen(S, Z=Z, dt=45.0, seed=3)
     w = mdl.weather_series(11, 45.0)
-    a0 = np.linspace(0., 30., 48)
-    b0 = np.linspace(0., 1., 48)
+    a0 = np.linspace(0., 30., Z)
+    b0 = np.linspace(0., 1., Z)
+    shared = list(shared)
     ref = st.copy()
     rc, iters = orc.OracleModel(md).march(ref, w, a0, b0)
     assert rc == 0
-    sm = ShardedMarch(md, 0, 1, device_index=0, collective="native", force_shared=[3, 20, 21, 47], fuse_always=True)
-    assert sm.n_shared_zones == 4 and sm.batch.n_fused_surfaces > 0
+    sm = ShardedMarch(md, 0, 1, device_index=0, collective="native", force_shared=shared, fuse_always=True)
+    assert sm.n_shared_zones == len(shared) and sm.batch.n_fused_surfaces > 0
     got = st.copy()
     sm.batch.upload_state(got)
     sm.march_resident(w[:5], a0, b0)
     sm.march_resident(w[5:], a0, b0)
     sm.synchronize()
     assert sm.batch.nomass_iterations() == iters
+    assert sm.batch.n_fused_launches > 0
     sm.batch.download_state(got)
     # the torch collective drives the split-phase calls: everything streamed there
-    sm2 = ShardedMarch(md, 0, 1, device_index=0, collective="torch", force_shared=[3, 20, 21, 47])
+    sm2 = ShardedMarch(md, 0, 1, device_index=0, collective="torch", force_shared=shared)
     got2 = st.copy()
     sm2.batch.upload_state(got2)
     sm2.march_resident(w, a0, b0)

@@ -30,6 +30,8 @@ def run_both(oracle, md, state0, weather, a0=None, b0=None, **opts):
         counts = b.class_counts()
         gpu_iters = b.nomass_iterations()
         n_fused = b.n_fused_surfaces
+        # (a planned cluster-resident march must really have run: calls of >= 3 sub-timesteps, or any in a small batch)
+        assert (b.n_fused_launches > 0) == (n_fused > 0 and (len(weather) >= 3 or md["n_surfaces"] <= 8192))
     if n_fused > 0 and "no_fusion" not in opts:
         # the planner sent (part of) this batch through the cluster-resident march: the streamed kernels of the
         # same batch are held to the same oracle
@@ -227,6 +229,22 @@ def test_sharded_march_single_rank_nccl():
     r = subprocess.run([sys.executable, os.path.join(here, "sharded_nccl_worker.py")], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "SHARDED OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_sharded_fused_launch_on_the_work_queue():
+    """Beside an exchange loop the fused launch holds fewer workgroups than it has FusedBlocks and hands them out
+    through a work queue (wavefronts without a tile keep step with the barriers). A full-size sharded batch does
+    that with 496 workgroups for 10 000 blocks; here the room is shrunk to 20 slots (HEAT_AMD_FUSED_ROOM) so that
+    4 workgroups march some 50 blocks, and the result is held to the oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HEAT_AMD_FUSED_ROOM="20", HEAT_AMD_TRACE="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "sharded_nccl_worker.py"), "queue"], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "SHARDED OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "fused launch on the work queue: 4 workgroups" in r.stderr, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("n,npl,which", [(3, 4, "both"), (5, 4, "front"), (9, 8, "back"), (9, 4, "both"), (17, 8, "both"),
@@ -484,6 +502,7 @@ def test_cluster_resident_march_matches_the_oracle_and_the_streamed_march(oracle
         b.march(got, w[9:10], a0, b0)             # ... of one ...
         b.march(got, w[10:], a0, b0)              # ... of 13
         assert b.nomass_iterations() == iters
+        assert b.n_fused_launches >= 3
     assert_state_close(md, ref, got)
     streamed = st.copy()
     with HeatBatch(md, nodes_per_lane=npl, no_fusion=True) as b:
@@ -529,6 +548,10 @@ def test_cluster_resident_march_with_gas_cavities(oracle):
     assert_state_close(md, ref, got)
     with HeatBatch(md, fuse_always=True) as b:
         assert b.n_fused_surfaces == 480, (b.n_fused_surfaces, b.class_counts())
+        b.upload_state(st.copy())
+        b.march_resident(w[:4])
+        b.synchronize()
+        assert b.n_fused_launches > 0
     streamed = st.copy()
     with HeatBatch(md, no_fusion=True) as b:
         b.upload_state(streamed)
@@ -559,6 +582,7 @@ def test_cluster_resident_march_of_rooms_with_windows(oracle, npl):
         b.march(got, w[:8], a0, b0)
         b.march(got, w[8:], a0, b0)
         assert b.nomass_iterations() == iters
+        assert (b.n_fused_launches > 0) == (b.n_fused_surfaces > 0)
     assert_state_close(md, ref, got)
     streamed = st.copy()
     with HeatBatch(md, nodes_per_lane=npl, no_fusion=True) as b:
