@@ -1235,7 +1235,8 @@ void enqueue_zones(heat_batch *b, int mode) {
 }
 
 // The cluster-resident march: every fused workgroup marches n_sub sub-timesteps in one launch per class.
-int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
+// streamed_beside: other surfaces of the batch are streamed on the batch's stream while this launch runs.
+int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside = false) {
     FusedArgs fa{};
     fa.zones = b->d_fzones.p;
     fa.zone_eoff = b->d_fzone_eoff.p;
@@ -1258,7 +1259,17 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
     // (measured: 27-74 us instead of 5) and become the critical path. So the launch holds a few workgroups fewer
     // than the chip has room for, and its workgroups take their FusedBlocks from a queue.
     static const int reserve_env = getenv("HEAT_AMD_FUSED_RESERVE") ? atoi(getenv("HEAT_AMD_FUSED_RESERVE")) : -1;
-    const bool beside_exchange = (b->comm != nullptr && b->shared_set && b->n_shared > 0) || reserve_env >= 0;
+    const bool beside_exchange = (b->comm != nullptr && b->shared_set && b->n_shared > 0) || reserve_env >= 0 || streamed_beside;
+    // share of the batch's padded nodes that is streamed beside this launch: that much of the chip is left to it
+    double streamed_share = 0.0;
+    if (streamed_beside) {
+        double ns = 4.0 * kWave * (b->n_gen_tiles - (b->n_small_tiles - b->n_small_plain_tiles - b->n_smallcav_stream_tiles)), nf = 0.0;
+        for (int c = 0; c < kNumFast; c++) {
+            ns += (double)b->n_stream_tiles[c] * kFastM[c] * kWave;
+            nf += (double)(b->n_fast_tiles[c] - b->n_stream_tiles[c]) * kFastM[c] * kWave;
+        }
+        streamed_share = ns / std::max(ns + nf, 1.0);
+    }
     static const int n_cu = [] {
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
@@ -1278,7 +1289,8 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st) {
                 const int fw = (g2 & 1) ? 8 : 4;
                 static const int room_env = getenv("HEAT_AMD_FUSED_ROOM") ? atoi(getenv("HEAT_AMD_FUSED_ROOM")) : 0;  // tests
                 const int room = room_env > 0 ? room_env : n_cu * fused_blocks_per_cu(kFastM[c], kFastCAV[c], g2 >> 1, fw);
-                const int reserve = reserve_env >= 0 ? reserve_env : (fw == 4 ? 16 : 8);
+                const int reserve = reserve_env >= 0 ? reserve_env
+                                                     : std::min(room / 2, std::max(fw == 4 ? 16 : 8, (int)(room * streamed_share)));
                 if (nb > room - reserve) {
                     grid = std::max(1, room - reserve);
                     fa.queue = b->d_fqueue.p + c * 4 + g2;
@@ -1782,7 +1794,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
             if (!e0 || !e1) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(e0, fs));
         }
-        rc = enqueue_fused(b, n_sub, fs);
+        rc = enqueue_fused(b, n_sub, fs, streamed);
         if (rc) return rc;
         if (b->timing) {
             HIP_TRY(hipEventRecord(e1, fs));
