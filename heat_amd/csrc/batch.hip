@@ -180,6 +180,8 @@ struct heat_batch {
     int n_stream_zones = 0;
     bool any_fused = false;
     hipEvent_t ev_fused = nullptr;
+    hipEvent_t ev_staged = nullptr;  // the H2D copies of a march call's weather / zone terms have run
+    bool staged = false;
     int n_fast_tiles[kNumFast] = {};
     DevBuf<FastTile> d_fast_tiles[kNumFast];
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
@@ -270,6 +272,7 @@ struct heat_batch {
         if (fused_stream) (void)hipStreamDestroy(fused_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_fused) (void)hipEventDestroy(ev_fused);
+        if (ev_staged) (void)hipEventDestroy(ev_staged);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1472,8 +1475,11 @@ int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n
     if (n_sub < 0) return fail(HEAT_E_INVALID_ARG, "n_sub < 0");
     int rc = select_device(b);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(b->stream));  // the pinned staging buffers are free again
+    // The pinned staging buffers are free again once the previous call's copies have run — they sit at the head of
+    // that call's work, so this does not wait for the march itself: consecutive marches queue up back to back.
+    if (b->staged) HIP_TRY(hipEventSynchronize(b->ev_staged));
     if ((size_t)n_sub > b->weather_cap) {
+        HIP_TRY(hipStreamSynchronize(b->stream));  // kernels in flight read the device array that is about to go
         if (b->h_weather) HIP_TRY(hipHostFree(b->h_weather));
         b->h_weather = nullptr;
         const size_t cap = std::max<size_t>((size_t)n_sub, 64);
@@ -1503,6 +1509,9 @@ int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n
         HIP_TRY(hipMemcpyAsync(b->d_zone_a0.p, b->h_zone_ab, Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
         HIP_TRY(hipMemcpyAsync(b->d_zone_b0.p, b->h_zone_ab + Z, Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
+    if (!b->ev_staged) HIP_TRY(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->ev_staged, b->stream));
+    b->staged = true;
     launch_set_step(b->d_step.p, 0, b->stream);
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
