@@ -1252,8 +1252,6 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
     fa.zone_T = b->d_zone_T.p;
     fa.dt = b->dt;
     fa.n_sub = n_sub;
-    static const int dbg = getenv("HEAT_AMD_FUSED_DEBUG") ? atoi(getenv("HEAT_AMD_FUSED_DEBUG")) : 0;
-    fa.pad = dbg;  // timing experiments only (results are wrong with any bit set): 1 no zone math, 2 no zone sums, 4 no barriers
     fa.gen_tiles = b->d_gen_tiles.p;
     fa.gen_base = b->gen_base;
     fa.small_iters = b->d_nomass_iters.p + b->nm_count_base[kNumFast];

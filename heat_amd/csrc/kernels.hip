@@ -351,9 +351,9 @@ __device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const Fu
 // (hs A, T) pairs are in LDS; one wavefront per zone sums them in the reference's order (model.rs:562-585).
 __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int wib,
                                                  int n_waves, int lane, int &bad_all) {
-    if (!(fa.pad & 4)) __syncthreads();
+    __syncthreads();
 #pragma clang loop unroll(disable)
-    for (int j = wib; j < blk.n_zones && !(fa.pad & 2); j += n_waves) {
+    for (int j = wib; j < blk.n_zones; j += n_waves) {
         const int e0 = l.zoff[j], e1 = l.zoff[j + 1];
         double a = 0.0, b = 0.0;
         for (int e = e0 + lane; e < e1; e += kWave) {
@@ -363,7 +363,7 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
         }
         a = wave_sum_f64(a);
         b = wave_sum_f64(b);
-        if (lane == 0 && !(fa.pad & 1)) {
+        if (lane == 0) {
             a += l.za0[j];
             b += l.zb0[j];
             const double tc = l.zT[j];
@@ -374,7 +374,7 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
             l.zT[j] = ft;
         }
     }
-    if (!(fa.pad & 4)) __syncthreads();
+    __syncthreads();
 }
 
 // A wavefront of small surfaces inside a fused workgroup: one lane per surface, everything in registers over
@@ -507,7 +507,8 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             if (fa.queue == nullptr) return;
             __syncthreads();
             for (int it = 0; it < fa.n_sub; it++) {
-                if (!(fa.pad & 4)) { __syncthreads(); __syncthreads(); }
+                __syncthreads();
+                __syncthreads();
             }
             goto next_block;
         }
@@ -708,9 +709,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
     };
     auto conv = [&](double air_t, double forced, double nat_pos, double nat_neg, double fix, double surf_t) {
-        double hs;
-        if (FUSED && (fa.pad & 8)) hs = forced + nat_pos * fabs(air_t - surf_t);  // (timing experiment: no cbrt)
-        else hs = forced + tarp_natural_coef(air_t, surf_t, nat_pos, nat_neg, bad);  // convection.rs:165-167
+        double hs = forced + tarp_natural_coef(air_t, surf_t, nat_pos, nat_neg, bad);  // convection.rs:165-167
         if (hs != hs) bad |= FLAG_NAN_HS;                                // surface.rs:704-707
         if (fix == fix) hs = fix;
         return hs;
