@@ -541,11 +541,15 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             return (int)blocks.size() - 1;
         };
         auto small_tiles = [](int n_small) { return (n_small + kWave - 1) / kWave; };
-        // The cluster-resident kernels are bound by instruction issue, not by HBM: cost per padded node by
-        // measured VALU instructions per node and sub-timestep (M = 16 : 8 : 4 = 0.76 : 1.11 : 1.9).
-        auto fused_cost = [&](int n, int m) {
-            const double w = (m == 4) ? 2.5 : (m == 8 ? 1.46 : 1.00);
-            return (double)((n + m - 1) / m * m) * w;
+        // Cost model (measured on MI355X, profiles/README.md). The cluster-resident march costs about 2 ns per tile
+        // (wavefront) and sub-timestep whatever the blocking factor — 1 M x 32: 40 000 tiles of 16-node lanes 82 us,
+        // 70 000 tiles of 8-node lanes 148 us; 1 M x 13: 40 000 tiles of 8-node lanes 72 us, 70 000 tiles of 4-node
+        // lanes 122 us — so the blocking factor that gives the fewest tiles is the best one, and a cluster is worth
+        // fusing when that beats what streaming it costs: its algorithmic bytes at the ~5.5 TB/s the streamed kernels
+        // sustain, plus k_zones' share.
+        constexpr double kFusedNsPerTile = 2.05, kStreamBytesPerNs = 5500.0, kZoneNs = 1.8;
+        auto fused_cost = [&](int n, int m) {  // (explicit nodes_per_lane, lone surfaces: lanes of the surface)
+            return (double)((n + m - 1) / m);
         };
         const int ms_all[3] = {4, 8, 16};
         for (int64_t r = 0; r < Z; r++) {
@@ -565,18 +569,20 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             int M = opt.nodes_per_lane;
             if (M == 16 && any_cav) continue;  // streamed
             if (M == 0) {
-                double best = 0.0;
-                for (int m : ms_all) {
+                int best_tiles = 0;
+                for (int m : ms_all) {  // fewest tiles wins; on a tie the larger lanes (fewer boundary evaluations)
                     if (m == 16 && any_cav) continue;
-                    double c = 0.0;
+                    int c_k[kWave + 1] = {};
                     bool ok = true;
-                    for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                    for (int64_t q = coff[r]; q < coff[r + 1] && ok; q++) {
                         if (is_small(csurf[q])) continue;
-                        const int n = placed[csurf[q]].n;
-                        ok = ok && (n + m - 1) / m >= 2;
-                        c += fused_cost(n, m);
+                        const int kk = (placed[csurf[q]].n + m - 1) / m;
+                        ok = kk >= 2 && kk <= kWave;
+                        if (ok) c_k[kk]++;
                     }
-                    if (ok && (M == 0 || c < best)) { M = m; best = c; }
+                    if (!ok) continue;
+                    const int t = tiles_needed(c_k);
+                    if (M == 0 || t <= best_tiles) { M = m; best_tiles = t; }
                 }
                 if (M == 0) M = 4;
             }
@@ -596,20 +602,22 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 ne > kFusedMaxEntries)
                 continue;  // streamed
             if (!fuse_always) {
-                // Cost model (measured, profiles/README.md): the resident march beats the streamed kernels only with
-                // 16 nodes per lane (2.1x on 1 M x 32; with 8 it is level, with 4 it loses), with well-filled
-                // wavefronts, and without glazing in the workgroup: a window's no-mass loop re-evaluates its gas
-                // cavity every pass (surface.rs:814) — a long serial chain the whole workgroup would wait for at
-                // every sub-timestep's barrier (rooms with double glazing: 8x slower fused than streamed).
-                int lanes = 0, n_cav_small = 0;
-                for (int k = 1; k <= kWave; k++) lanes += cnt[k] * k;
-                for (int64_t q = coff[r]; q < coff[r + 1]; q++) n_cav_small += cat[csurf[q]].kind == kSmallCav;
-                const int tiles = tiles_needed(cnt);
+                // No glazing in a fused workgroup: a window's no-mass loop re-evaluates its gas cavity every pass
+                // (surface.rs:814) — a long serial chain the whole workgroup would wait for at every sub-timestep's
+                // barrier (rooms with double glazing: 8x slower fused than streamed). Otherwise: tiles against bytes.
+                int n_cav_small = 0;
+                double bytes = 0.0;
+                for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
+                    n_cav_small += cat[csurf[q]].kind == kSmallCav;
+                    bytes += 32.0 * placed[csurf[q]].n + 152.0;
+                }
+                const int tiles = tiles_needed(cnt) + small_tiles(n_small);
                 // A small batch is bound by launches and latency, not by throughput: there the resident march wins
                 // with any blocking factor (one launch per march call instead of two or more per sub-timestep).
                 const bool small_batch = S <= 8192;
                 if (n_cav_small > 0 || tiles == 0) continue;                                        // streamed
-                if (!small_batch && (M != 16 || lanes < 0.6 * kWave * tiles)) continue;             // streamed
+                if (!small_batch && kFusedNsPerTile * tiles > 0.85 * (bytes / kStreamBytesPerNs + kZoneNs * nz))
+                    continue;                                                                       // streamed
             }
             Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1};
             const int cls = fast_class(M, cc);
@@ -653,10 +661,11 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             if (M == 0) {
                 M = 4;
                 for (int m : {8, 16})
-                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) < fused_cost(pl.n, M)) M = m;
+                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
-            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && M != 16 && S > 8192)) { lone_ok[s] = 0; continue; }
+            const bool gains = kFusedNsPerTile * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
+            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
             pl.k = k;
         }
@@ -679,13 +688,19 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             }
         }
     }
-    if (fuse && !fuse_always && S <= 8192 && !blocks.empty()) {
-        // A small batch gains from the resident march only when NOTHING is left to stream: the streamed remainder
-        // would still pay its launches and latencies every sub-timestep (and wait for slots beside the fused launch;
-        // measured, 2 000 clustered walls of which 733 fused: 89 us per sub-timestep against 64 all streamed).
+    if (fuse && !fuse_always && !blocks.empty()) {
+        // Fusing part of a batch does not pay: the streamed remainder still pays its launches and latencies every
+        // sub-timestep, and the two kinds of kernels share the chip badly (measured: 2 000 clustered walls with 733
+        // of them fused 89 us per sub-timestep against 64 all streamed; 1 M clustered walls with 205 000 fused 260
+        // against 222). A small batch is fused only as a whole, a large one when at least nine tenths of its nodes are.
+        double fused_nodes = 0.0, all_nodes = 0.0;
         bool remainder = false;
-        for (int64_t s = 0; s < S && !remainder; s++) remainder = placed[s].blk < 0;
-        if (remainder) {
+        for (int64_t s = 0; s < S; s++) {
+            all_nodes += placed[s].n;
+            if (placed[s].blk >= 0) fused_nodes += placed[s].n;
+            else remainder = true;
+        }
+        if (S <= 8192 ? remainder : fused_nodes < 0.9 * all_nodes) {
             placed = placed_streamed;
             blocks.clear();
         }
