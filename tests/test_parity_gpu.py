@@ -647,3 +647,47 @@ def test_config3_at_full_size_fast_kernels_equal_the_catch_all_kernel():
     assert res[0][1] == res[1][1] > 0
     assert np.all(np.isfinite(res[0][0]))
     assert np.allclose(res[0][0], res[1][0], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_planner_stress_random_zone_graphs(oracle, seed):
+    """Random small models — walls, facings, windows, partitions, walls between random pairs of zones, zones nobody faces,
+    walls facing the same zone on both sides, walls facing no zone — through every planner mode (cost model, everything
+    that can be fused, nothing fused) and blocking factor: the same state as the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    S = int(rng.integers(60, 900))
+    Z = int(rng.integers(3, 40))
+    gen = mdl.rooms_with_windows if seed % 2 else mdl.clustered_massive
+    md, st = gen(S, Z=Z, dt=45.0, seed=seed)
+    # rewire some walls: random zone pairs (longer chains of zones), same zone on both sides, no zone at all
+    pick = rng.random(S)
+    both = (md["front_kind"] == mdl.SPACE) & (md["back_kind"] == mdl.SPACE)
+    rew = both & (pick < 0.3)
+    md["front_zone"] = np.where(rew, rng.integers(0, Z, S), md["front_zone"]).astype(np.int32)
+    same = both & (pick > 0.9)
+    md["front_zone"] = np.where(same, md["back_zone"], md["front_zone"]).astype(np.int32)
+    nodes = np.diff(md["node_offset"])
+    lone = (pick > 0.5) & (pick < 0.56) & (nodes > 4)
+    md["front_kind"] = np.where(lone, mdl.AMBIENT, md["front_kind"]).astype(np.int32)
+    md["back_kind"] = np.where(lone, mdl.OUTDOOR, md["back_kind"]).astype(np.int32)
+    md["front_ambient"] = np.where(lone, 12.5, md["front_ambient"])
+    w = mdl.weather_series(9, 45.0, wind_speed=float(rng.uniform(0.5, 6.0)), wind_deg=float(rng.uniform(0, 360)))
+    a0 = rng.uniform(0., 50., Z)
+    b0 = rng.uniform(0., 2., Z)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    npl = [0, 4, 8, 16][seed % 4]
+    fused_counts = []
+    for kw in (dict(), dict(fuse_always=True), dict(no_fusion=True), dict(fuse_always=True, nodes_per_lane=npl)):
+        got = st.copy()
+        with HeatBatch(md, **kw) as b:
+            b.upload_state(got)
+            b.march(got, w[:4], a0, b0)
+            b.march(got, w[4:], a0, b0)
+            assert b.nomass_iterations() == iters, kw
+            assert (b.n_fused_launches > 0) == (b.n_fused_surfaces > 0), kw
+            fused_counts.append(b.n_fused_surfaces)
+        assert_state_close(md, ref, got)
+    print("seed %d: S=%d Z=%d fused surfaces by mode %s" % (seed, S, Z, fused_counts))
+    assert fused_counts[2] == 0 and fused_counts[1] >= fused_counts[0]
