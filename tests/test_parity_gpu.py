@@ -691,3 +691,24 @@ def test_planner_stress_random_zone_graphs(oracle, seed):
         assert_state_close(md, ref, got)
     print("seed %d: S=%d Z=%d fused surfaces by mode %s" % (seed, S, Z, fused_counts))
     assert fused_counts[2] == 0 and fused_counts[1] >= fused_counts[0]
+
+
+def test_long_march_stays_within_tolerance(oracle):
+    """3 000 sub-timesteps (37.5 simulated hours at dt = 45 s, a full day of the weather cycle) in march calls of 100:
+    the cluster-resident march, the streamed march and the oracle stay within the parity tolerance — rounding
+    differences do not accumulate (the conduction operator is contractive)."""
+    md, st = mdl.clustered_massive(400, Z=16, dt=45.0, seed=8)
+    w = mdl.weather_series(3000, 45.0, wind_speed=3.0, wind_deg=210.0)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w)
+    assert rc == 0
+    for kw in (dict(fuse_always=True), dict(no_fusion=True)):
+        got = st.copy()
+        with HeatBatch(md, use_graph=True, **kw) as b:
+            b.upload_state(got)
+            for i in range(0, 3000, 100):
+                b.march_resident(w[i:i + 100])
+            b.synchronize()
+            b.download_state(got)
+            assert b.nomass_iterations() == iters
+        assert_state_close(md, ref, got)
