@@ -355,6 +355,9 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
 #pragma clang loop unroll(disable)
     for (int j = wib; j < blk.n_zones; j += n_waves) {
         const int e0 = l.zoff[j], e1 = l.zoff[j + 1];
+        // (the capacitance does not wait for the sums: its division overlaps their LDS round trips)
+        const double tc = l.zT[j];
+        const double cz = zone_mcp(l.zvol[j], tc);  // model.rs:549-552
         double a = 0.0, b = 0.0;
         for (int e = e0 + lane; e < e1; e += kWave) {
             const double2 ht = l.hT[l.slots[e]];
@@ -366,8 +369,6 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
         if (lane == 0) {
             a += l.za0[j];
             b += l.zb0[j];
-            const double tc = l.zT[j];
-            const double cz = zone_mcp(l.zvol[j], tc);  // model.rs:549-552
             double ft = tc;
             if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * fa.dt / cz);  // model.rs:662-666
             if (ft != ft) bad_all |= FLAG_NAN_ZONE;                                // model.rs:417-420
@@ -1174,12 +1175,23 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
     if (z >= n_zones) return;
     double a = 0.0, b = 0.0;
     const int64_t e0 = zone_off[z], e1 = zone_off[z + 1];
-    for (int64_t e = e0 + lane; e < e1; e += kWave) {  // model.rs:562-585
-        const ZoneEntry en = entries[e];
-        const double h = out[en.hs_index].hs;
-        const double ha = h * en.area;
-        a += ha * T[en.t_index];
-        b += ha;
+    // the zone's own terms are fetched beside the first entries (their latency is then off the serial tail)
+    const double za0 = a0[z], zb0 = b0[z], tc = zone_T[z], zv = zone_vol[z];
+    // two entries per lane and pass: both chains of dependent gathers (entry -> hs, T) are in flight together
+    for (int64_t e = e0 + lane; e < e1; e += 2 * kWave) {  // model.rs:562-585
+        const bool two = e + kWave < e1;
+        const ZoneEntry en0 = entries[e];
+        const ZoneEntry en1 = entries[two ? e + kWave : e];
+        const double h0 = out[en0.hs_index].hs, h1 = out[en1.hs_index].hs;
+        const double t0 = T[en0.t_index], t1 = T[en1.t_index];
+        const double ha0 = h0 * en0.area;
+        a += ha0 * t0;
+        b += ha0;
+        if (two) {
+            const double ha1 = h1 * en1.area;
+            a += ha1 * t1;
+            b += ha1;
+        }
     }
     a = wave_sum_f64(a);  // fixed tree: run-to-run deterministic
     b = wave_sum_f64(b);
@@ -1197,10 +1209,9 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
             return;
         }
     }
-    a += a0[z];
-    b += b0[z];
-    const double tc = zone_T[z];
-    const double c = zone_mcp(zone_vol[z], tc);  // model.rs:549-552
+    a += za0;
+    b += zb0;
+    const double c = zone_mcp(zv, tc);  // model.rs:549-552
     double ft = tc;
     if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);  // model.rs:662-666
     if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);                      // model.rs:417-420
