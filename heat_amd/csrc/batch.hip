@@ -541,13 +541,19 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             return (int)blocks.size() - 1;
         };
         auto small_tiles = [](int n_small) { return (n_small + kWave - 1) / kWave; };
-        // Cost model (measured on MI355X, profiles/README.md). The cluster-resident march costs about 2 ns per tile
-        // (wavefront) and sub-timestep whatever the blocking factor — 1 M x 32: 40 000 tiles of 16-node lanes 82 us,
-        // 70 000 tiles of 8-node lanes 148 us; 1 M x 13: 40 000 tiles of 8-node lanes 72 us, 70 000 tiles of 4-node
-        // lanes 122 us — so the blocking factor that gives the fewest tiles is the best one, and a cluster is worth
-        // fusing when that beats what streaming it costs: its algorithmic bytes at the ~5.5 TB/s the streamed kernels
-        // sustain, plus k_zones' share.
-        constexpr double kFusedNsPerTile = 2.05, kStreamBytesPerNs = 5500.0, kZoneNs = 1.8;
+        // Cost model (measured on MI355X, profiles/README.md): what the cluster-resident march of a cluster costs by
+        // blocking factor and tile count (below) against what streaming it costs — its algorithmic bytes at the
+        // ~5.5 TB/s the streamed kernels sustain, plus k_zones' share. The cheapest blocking factor is taken.
+        constexpr double kStreamBytesPerNs = 5500.0, kZoneNs = 1.8;
+        // ns per cluster and sub-timestep. Up to four tiles (two or three workgroups per compute unit): per tile —
+        // 16 nodes per lane 2.05 (1 M x 32: 82 us / 40 000 tiles), 8: 1.8 (1 M x 13: 72 us), 4: 1.15 (1 M x 8: 46 us).
+        // Five to eight tiles (a workgroup has a compute unit to itself, however many of its wavefronts work): per
+        // workgroup — 16: 16.5 (1 M x 48: 165 us / 10 000), 8: 14.8 (1 M x 32: 148 us), 4: 12 (1 M x 10: 118 us).
+        auto cluster_ns = [](int m, int tiles) {
+            if (tiles <= 4) return tiles * (m == 16 ? 2.05 : (m == 8 ? 1.8 : 1.15));
+            return m == 16 ? 16.5 : (m == 8 ? 14.8 : 12.0);
+        };
+        auto tile_ns = [](int m) { return m == 16 ? 2.05 : (m == 8 ? 1.8 : 1.15); };  // (surfaces that face no zone)
         auto fused_cost = [&](int n, int m) {  // (explicit nodes_per_lane, lone surfaces: lanes of the surface)
             return (double)((n + m - 1) / m);
         };
@@ -569,8 +575,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             int M = opt.nodes_per_lane;
             if (M == 16 && any_cav) continue;  // streamed
             if (M == 0) {
-                int best_tiles = 0;
-                for (int m : ms_all) {  // fewest tiles wins; on a tie the larger lanes (fewer boundary evaluations)
+                double best_cost = 0.0;
+                for (int m : ms_all) {  // cheapest tiles win; on a tie the larger lanes
                     if (m == 16 && any_cav) continue;
                     int c_k[kWave + 1] = {};
                     bool ok = true;
@@ -581,8 +587,10 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                         if (ok) c_k[kk]++;
                     }
                     if (!ok) continue;
-                    const int t = tiles_needed(c_k);
-                    if (M == 0 || t <= best_tiles) { M = m; best_tiles = t; }
+                    const int nt_m = tiles_needed(c_k) + small_tiles(n_small);
+                    if (nt_m > kFusedMaxWaves) continue;
+                    const double t = cluster_ns(m, nt_m);
+                    if (M == 0 || t <= best_cost) { M = m; best_cost = t; }
                 }
                 if (M == 0) M = 4;
             }
@@ -616,7 +624,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                 // with any blocking factor (one launch per march call instead of two or more per sub-timestep).
                 const bool small_batch = S <= 8192;
                 if (n_cav_small > 0 || tiles == 0) continue;                                        // streamed
-                if (!small_batch && kFusedNsPerTile * tiles > 0.85 * (bytes / kStreamBytesPerNs + kZoneNs * nz))
+                if (!small_batch && cluster_ns(M, tiles) > 0.85 * (bytes / kStreamBytesPerNs + kZoneNs * nz))
                     continue;                                                                       // streamed
             }
             Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1};
@@ -664,7 +672,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
                     if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
-            const bool gains = kFusedNsPerTile * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
+            const bool gains = tile_ns(M) * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
             if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
             pl.k = k;
