@@ -52,6 +52,34 @@ def build_shard(S, n, zones_per_gpu, rank, world, dt, seed):
     return md, state
 
 
+CONFIGS = ("headline", "2", "3", "5", "partitions")
+
+
+def build_config(name, args, rank, world, dt, seed):
+    """The workloads of BASELINE.json / SURVEY.md §8(d). Returns (model dict, initial state, description)."""
+    from heat_amd import modeldict as mdl
+    if name == "headline":
+        md, state = build_shard(args.surfaces, args.nodes, args.zones_per_gpu, rank, world, dt, seed)
+        return md, state, ("north_star headline: %d all-massive surfaces x %d nodes per GPU, RK4 + TARP convection + "
+                           "long-wave + solar boundaries, %d zones per GPU, dt = %g s" % (
+                               args.surfaces, args.nodes, args.zones_per_gpu, dt))
+    if name == "2":
+        md, state = mdl.uniform_massive(10_000, 20, Z=100, dt=90.0, identical=True, vertical=True)
+        return md, state, "BASELINE config 2: 10 000 identical 3-layer massive walls x 20 nodes, 100 zones, dt = 90 s"
+    if name == "3":
+        S = args.surfaces
+        md, state = mdl.ragged_mixed(S, Z=max(1, S // 100), dt=dt, seed=seed)
+        return md, state, ("BASELINE config 3: %d ragged surfaces of 8-64 nodes (70 %% massive, 20 %% massive core "
+                           "between no-mass facings, 10 %% two-node no-mass), mixed boundaries, %d zones joined in a "
+                           "ring by the Space/Space walls, dt = %g s" % (S, max(1, S // 100), dt))
+    if name == "5":
+        S = 200_000 if args.surfaces == 1_000_000 else args.surfaces
+        md, state = mdl.glazing_cavity(S, Z=max(1, S // 100), dt=dt)
+        return md, state, ("BASELINE config 5: %d surfaces, half double glazing (4 no-mass nodes around a gas cavity), "
+                           "half Trombe-like (concrete / air cavity / glass, 17 nodes), dt = %g s" % (S, dt))
+    raise SystemExit("unknown --config %r" % name)
+
+
 def cpu_baseline(n, dt, seed, target_seconds=12.0):
     """Times the oracle (single thread: the reference is single-threaded, model.rs:113-116) on a
     bounded sample of the same workload."""
@@ -151,6 +179,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=CONFIGS, default="headline",
+                    help="workload: the north_star headline (default) or a BASELINE.json config")
     ap.add_argument("--surfaces", type=int, default=1_000_000, help="surfaces per GPU")
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--zones-per-gpu", type=int, default=10_000)
@@ -188,7 +218,8 @@ def main():
     seed = 20260401
 
     from heat_amd import HeatBatch, modeldict as mdl
-    md, state = build_shard(args.surfaces, args.nodes, args.zones_per_gpu, rank, world, dt, seed)
+    md, state, workload = build_config(args.config, args, rank, world, dt, seed)
+    dt = float(md["dt"])
     n_nodes_local = int(md["node_offset"][-1])
     weather_w = mdl.weather_series(max(W, 1), dt)
     weather_k = mdl.weather_series(K, dt, t0=dt * W)
@@ -267,11 +298,10 @@ def main():
         "data": "synthetic",
         "sub_timesteps_per_sec": K / elapsed,
         "config": {
-            "workload": "north_star headline: %d all-massive surfaces x %d nodes per GPU, RK4 + TARP convection + "
-                        "long-wave + solar boundaries, %d zones per GPU, dt = %g s; one step = one sub-timestep "
-                        "(iterate_surfaces + zone update)" % (args.surfaces, args.nodes, args.zones_per_gpu, dt),
-            "surfaces_per_gpu": args.surfaces, "nodes_per_surface": args.nodes,
-            "zones_per_gpu": args.zones_per_gpu, "dt_s": dt, "substeps_per_march": P,
+            "workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
+            "config": args.config,
+            "surfaces_per_gpu": int(md["n_surfaces"]), "nodes_per_gpu": n_nodes_local,
+            "zones_per_gpu": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
             "kernel_classes[M4,M8,M16,small,general]": counts,
             "surfaces_in_cluster_resident_march": n_fused,
             "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep RCCL all-gather of the partial "

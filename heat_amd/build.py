@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libheat_amd.so")
-SOURCES = ["kernels.hip", "batch.hip", "setup.cpp"]
-HEADERS = ["layout.hpp", "kernels.hpp", "device_math.hpp", os.path.join("..", "..", "include", "heat_amd.h"),
+SOURCES = ["kernels.hip", "batch.hip", "plan.cpp", "setup.cpp"]
+HEADERS = ["layout.hpp", "kernels.hpp", "device_math.hpp", "plan.hpp", os.path.join("..", "..", "include", "heat_amd.h"),
            os.path.join("..", "..", "include", "heat_amd_setup.h")]
 
 

@@ -22,6 +22,7 @@
 #include "../../include/heat_amd.h"
 #include "kernels.hpp"
 #include "layout.hpp"
+#include "plan.hpp"
 
 using namespace heat;
 
@@ -119,19 +120,7 @@ struct DevBuf {
     }
 };
 
-constexpr int kMaxNodesGeneral = 4096;
 constexpr int kFusedMinSubsteps = 3;  // march calls of fewer sub-timesteps are streamed (large batches)
-constexpr int kScratchArrays = 7;
-// fast classes: index = mi * 6 + nm * 3 + v;  M = 4 << mi;  nm: no-mass facings allowed;
-// v = 0 per-node arrays, 1 palette constants, 2 palette + gas cavities between massive nodes
-constexpr int kNumFast = 18;
-const int kFastM[kNumFast] = {4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 16, 16, 16, 16, 16, 16};
-const int kFastNM[kNumFast] = {0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1};
-const int kFastPAL[kNumFast] = {0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1};
-const int kFastCAV[kNumFast] = {0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
-constexpr int kSmall = kNumFast;         // all-no-mass surfaces of <= 4 nodes (general layout, register kernel)
-constexpr int kSmallCav = kNumFast + 1;  // ... with a gas cavity (double glazing)
-constexpr int kGeneral = kNumFast + 2;   // catch-all
 
 }  // namespace
 
@@ -211,6 +200,7 @@ struct heat_batch {
     DevBuf<int64_t> d_first_slot, d_slots;  // d_slots: 8 arrays of n_surf
     DevBuf<int64_t> d_zone_slot, d_zone_off;
     DevBuf<ZoneEntry> d_zone_entries;
+    DevBuf<ZoneContrib> d_zone_contrib;  // [zone entries], written by the surface kernels
     DevBuf<double> d_zone_vol, d_zone_T, d_zone_a0, d_zone_b0, d_partial;
     double *partial_ptr = nullptr;  // where step_surfaces writes (a, b): d_partial or caller memory
     // sharded batches (heat_batch_set_shared_zones)
@@ -279,171 +269,6 @@ struct heat_batch {
 
 namespace {
 
-struct Placed {
-    int64_t s;   // original surface index
-    int n;       // node count
-    int cls;     // 0..kNumFast-1 fast classes, kGeneral = catch-all
-    int k;       // lanes per surface (fast)
-    int blk;     // cluster-resident march: workgroup number, -1 = streamed
-};
-
-// Tiles a set of fast-path surfaces needs: surfaces of equal k share a tile, floor(64 / k) per tile.
-int tiles_needed(const int (&cnt)[kWave + 1]) {
-    int t = 0;
-    for (int k = 1; k <= kWave; k++)
-        if (cnt[k]) t += (cnt[k] + kWave / k - 1) / (kWave / k);
-    return t;
-}
-
-// What kind of kernel a surface needs (before the blocking factor M is chosen).
-struct Category {
-    int kind;  // kSmall, kSmallCav, kGeneral, or 0 = fast path
-    int nm;    // fast: has a no-mass facing node
-    int ncav;  // fast: gas cavities between massive nodes
-    int pal;   // fast: the per-node constants fit a palette
-};
-
-// Decides whether a surface can take the register-resident fast path:
-// solid conductances only, solar absorbed at the two faces only, every interior node massive; the
-// face nodes may be no-mass facings (each then is an isolated one-node no-mass chunk).
-Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
-    Category r{kGeneral, 0, 0, 0};
-    if (opt.force_general) return r;
-    const int64_t o = d->node_offset[s];
-    if (n <= 4) {
-        bool all_nomass = true;
-        for (int i = 0; i < n; i++) all_nomass = all_nomass && (d->mass[o + i] < kMassThreshold);
-        bool has_cav = false;
-        for (int i = 0; i < n; i++)
-            has_cav = has_cav || (d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0);
-        if (all_nomass) {
-            r.kind = has_cav ? kSmallCav : kSmall;
-            return r;
-        }
-    }
-    if (n < 2) return r;
-    int nm = 0, ncav = 0;
-    auto is_cav = [&](int i) { return d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0; };
-    for (int i = 0; i < n; i++) {
-        if (d->mass[o + i] < kMassThreshold) {
-            if (i != 0 && i != n - 1) return r;                        // no-mass node inside
-            nm = 1;
-        }
-        if (is_cav(i)) {
-            // a cavity on the fast path sits between two massive nodes (its conductance is then needed
-            // once per sub-timestep, not once per pass of a no-mass loop)
-            if (i + 1 >= n || d->mass[o + i] < kMassThreshold || d->mass[o + i + 1] < kMassThreshold) return r;
-            if (++ncav > 2) return r;
-        }
-        if (i > 0 && d->front_alpha[o + i] != 0.0) return r;           // solar absorbed inside
-        if (i < n - 1 && d->back_alpha[o + i] != 0.0) return r;
-    }
-    if (n == 2 && d->mass[o] < kMassThreshold && d->mass[o + 1] < kMassThreshold) return r;  // 2-node chunk
-    // Palette form when the wall has few distinct constants (entry 0 of each palette is 0.0).
-    int pal = opt.no_palette ? 0 : 1;
-    if (pal) {
-        double vv[kPalV], uu[kPalU];
-        int nv = 1, nu = 1;
-        vv[0] = 0.0;
-        uu[0] = 0.0;
-        for (int i = 0; i < n && pal; i++) {
-            const double mass = d->mass[o + i];
-            const double v = (mass >= kMassThreshold) ? d->dt / mass : 0.0;
-            const double u = is_cav(i) ? 0.0 : d->uvalue[o + i];
-            int f = -1;
-            for (int q = 0; q < nv; q++) if (vv[q] == v) f = q;
-            if (f < 0) { if (nv == kPalV) pal = 0; else vv[nv++] = v; }
-            f = -1;
-            for (int q = 0; q < nu; q++) if (uu[q] == u) f = q;
-            if (f < 0) { if (nu == kPalU) pal = 0; else uu[nu++] = u; }
-        }
-    }
-    if (ncav > 0 && !pal) return r;  // the cavity variant exists in palette form only
-    r.kind = 0;
-    r.nm = nm;
-    r.ncav = ncav;
-    r.pal = pal;
-    return r;
-}
-
-// Nodes are padded to a multiple of M inside the last lane. Measured cost per padded node
-// (1 M x 32 and 1 M x 20 nodes, profiles/README.md): M = 16 : 8 : 4 = 1.00 : 1.03 : 1.30 — larger blocks
-// amortise the per-surface boundary work over more nodes.
-double padded_cost(int n, int M) {
-    const double w = (M == 4) ? 1.30 : (M == 8 ? 1.03 : 1.00);
-    return (double)((n + M - 1) / M * M) * w;
-}
-
-int choose_M(int n, const heat_batch_options &opt) {
-    if (opt.nodes_per_lane != 0) return opt.nodes_per_lane;
-    int M = 4;
-    for (int m : {8, 16})
-        if (padded_cost(n, m) < padded_cost(n, M)) M = m;
-    return M;
-}
-
-int fast_class(int M, const Category &c) { return (M == 4 ? 0 : (M == 8 ? 6 : 12)) + c.nm * 3 + (c.ncav > 0 ? 2 : c.pal); }
-
-int check_desc(const heat_batch_desc *d) {
-    if (!d) return fail(HEAT_E_INVALID_ARG, "descriptor is NULL");
-    if (d->abi_version != HEAT_AMD_ABI_VERSION)
-        return fail(HEAT_E_INVALID_ARG, "abi_version %d, library is %d", d->abi_version, HEAT_AMD_ABI_VERSION);
-    if (d->n_surfaces < 0 || d->n_zones < 0 || d->n_cavities < 0 || d->n_state < 0)
-        return fail(HEAT_E_INVALID_ARG, "negative count in descriptor");
-    if (!(d->dt > 0.0)) return fail(HEAT_E_INVALID_ARG, "dt must be positive");
-    const void *need[] = {d->node_offset, d->mass, d->uvalue, d->front_alpha, d->back_alpha, d->front_kind,
-                          d->back_kind, d->front_zone, d->back_zone, d->front_ambient, d->back_ambient,
-                          d->front_emissivity, d->back_emissivity, d->area, d->perimeter, d->cos_tilt,
-                          d->normal_x, d->normal_y, d->wind_modifier, d->first_node_slot, d->hs_front_slot,
-                          d->hs_back_slot, d->flow_front_slot, d->flow_back_slot, d->solar_front_slot,
-                          d->solar_back_slot, d->ir_front_slot, d->ir_back_slot};
-    if (d->n_surfaces > 0)
-        for (const void *p : need)
-            if (!p) return fail(HEAT_E_INVALID_ARG, "a required per-surface array is NULL");
-    if (d->n_zones > 0 && (!d->zone_volume || !d->zone_slot))
-        return fail(HEAT_E_INVALID_ARG, "zone arrays are NULL");
-    if (d->n_cavities > 0 && (!d->cavities || !d->seg_cavity))
-        return fail(HEAT_E_INVALID_ARG, "cavity arrays are NULL");
-    if ((d->front_hs_fix == nullptr) != (d->back_hs_fix == nullptr))
-        return fail(HEAT_E_INVALID_ARG, "front_hs_fix and back_hs_fix must both be given or both be NULL");
-    const int64_t ns = d->n_state;
-    auto slot_ok = [&](int64_t v) { return v >= 0 && v < ns; };
-    for (int64_t z = 0; z < d->n_zones; z++)
-        if (!slot_ok(d->zone_slot[z])) return fail(HEAT_E_SIZE, "zone %lld: slot out of range", (long long)z);
-    if (d->n_surfaces > 0 && d->node_offset[0] != 0) return fail(HEAT_E_INVALID_ARG, "node_offset[0] != 0");
-    for (int64_t s = 0; s < d->n_surfaces; s++) {
-        const int64_t n = d->node_offset[s + 1] - d->node_offset[s];
-        if (n < 1) return fail(HEAT_E_INVALID_ARG, "surface %lld has %lld nodes", (long long)s, (long long)n);
-        if (n > kMaxNodesGeneral)
-            return fail(HEAT_E_TOO_MANY_NODES, "surface %lld has %lld nodes (max %d)", (long long)s, (long long)n,
-                        kMaxNodesGeneral);
-        const int fk = d->front_kind[s], bk = d->back_kind[s];
-        if (fk == HEAT_BOUNDARY_GROUND || bk == HEAT_BOUNDARY_GROUND)
-            return fail(HEAT_E_GROUND_BOUNDARY, "surface %lld: Ground boundary is not supported (reference panics)", (long long)s);
-        if (fk < 0 || fk > 2 || bk < 0 || bk > 2)
-            return fail(HEAT_E_INVALID_ARG, "surface %lld: unknown boundary kind", (long long)s);
-        if (fk == HEAT_BOUNDARY_SPACE && (d->front_zone[s] < 0 || d->front_zone[s] >= d->n_zones))
-            return fail(HEAT_E_SIZE, "surface %lld: front zone out of range", (long long)s);
-        if (bk == HEAT_BOUNDARY_SPACE && (d->back_zone[s] < 0 || d->back_zone[s] >= d->n_zones))
-            return fail(HEAT_E_SIZE, "surface %lld: back zone out of range", (long long)s);
-        if (d->first_node_slot[s] < 0 || d->first_node_slot[s] + n > ns)
-            return fail(HEAT_E_SIZE, "surface %lld: node slots out of range", (long long)s);
-        if (!slot_ok(d->hs_front_slot[s]) || !slot_ok(d->hs_back_slot[s]) || !slot_ok(d->flow_front_slot[s]) ||
-            !slot_ok(d->flow_back_slot[s]) || !slot_ok(d->solar_front_slot[s]) || !slot_ok(d->solar_back_slot[s]) ||
-            !slot_ok(d->ir_front_slot[s]) || !slot_ok(d->ir_back_slot[s]))
-            return fail(HEAT_E_SIZE, "surface %lld: scalar slot out of range", (long long)s);
-        const int64_t o = d->node_offset[s];
-        for (int64_t i = 0; i < n; i++) {
-            const bool cav = d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0;
-            if (cav && d->seg_cavity[o + i] >= d->n_cavities)
-                return fail(HEAT_E_SIZE, "surface %lld: cavity index out of range", (long long)s);
-            if (!cav && std::isnan(d->uvalue[o + i]))
-                return fail(HEAT_E_UVALUE_NONE, "surface %lld node %lld: UValue::None", (long long)s, (long long)i);
-        }
-    }
-    return HEAT_OK;
-}
-
 int flags_to_status(int f) {
     if (f & FLAG_NAN_HS) return fail(HEAT_N_NAN_HS, "NaN convection coefficient (reference: surface.rs:704)");
     if (f & FLAG_NAN_NOMASS) return fail(HEAT_N_NAN_NOMASS, "NaN error in the no-mass loop (reference: surface.rs:850)");
@@ -453,703 +278,102 @@ int flags_to_status(int f) {
 }
 
 int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt) {
-    const int64_t S = d->n_surfaces, Z = d->n_zones;
+    // Classification, clustering, tiling and packing are host-only work (plan.cpp); here the plan is uploaded.
+    Plan p;
+    {
+        std::string err;
+        const int rc = make_plan(d, opt, p, err);
+        if (rc) return fail(rc, "%s", err.c_str());
+    }
+    const int64_t S = p.n_surf, Z = p.n_zones;
     b->n_surf = S;
     b->n_zones = Z;
-    b->n_state = d->n_state;
-    b->n_cav = d->n_cavities;
-    b->dt = d->dt;
-    b->n_nodes = S > 0 ? d->node_offset[S] : 0;
-    b->algorithmic_bytes = 32 * b->n_nodes + 152 * S;  // 32 n + 152 bytes per surface per sub-timestep
-
-    // ---- classify ----
-    std::vector<Placed> placed(S);
-    std::vector<Category> cat(S);
-    for (int64_t s = 0; s < S; s++) {
-        const int n = (int)(d->node_offset[s + 1] - d->node_offset[s]);
-        cat[s] = categorize(d, s, n, opt);
-        int cls = cat[s].kind, k = 1;
-        if (cat[s].kind == 0) {
-            const int M = choose_M(n, opt);
-            k = (n + M - 1) / M;
-            cls = (k > kWave) ? kGeneral : fast_class(M, cat[s]);
-            if (k > kWave) { cat[s].kind = kGeneral; k = 1; }
-        }
-        placed[s] = Placed{s, n, cls, k, -1};
-    }
-
-    // ---- cluster-resident march: zone-connected clusters -> workgroups (layout.hpp, FusedBlock) ----
-    // A cluster is a connected component of the graph "zone - surface facing it"; its surfaces exchange heat
-    // only through its own zones (model.rs:556-590), so a workgroup that holds all of them can march any number
-    // of sub-timesteps without leaving the chip. A cluster is fused when every surface of it is a palette-form
-    // fast-path wall without cavities and it fits kFusedMaxWaves tiles / kFusedMaxZones zones; its surfaces then
-    // share one blocking factor (4 or 8: the 16-node variant does not fit the register file with the state that
-    // lives across sub-timesteps). Surfaces that face no zone at all are clusters of one and are packed freely.
-    struct BlockPlan { int cls; bool mixed; std::vector<int32_t> zones; };  // mixed: holds small-surface tiles too
-    std::vector<BlockPlan> blocks;
-    // no_fusion: 0 = fuse the clusters the cost model below expects to gain, 1 = never, 2 = every cluster that can be
-    const bool fuse = opt.no_fusion != 1 && !opt.force_general && !opt.no_palette;
-    const bool fuse_always = opt.no_fusion == 2;
-    const std::vector<Placed> placed_streamed = placed;  // the plan without any cluster-resident march
-    if (fuse && S > 0) {
-        auto is_small = [&](int64_t s) { return cat[s].kind == kSmall || cat[s].kind == kSmallCav; };
-        auto fusable = [&](int64_t s) { return (cat[s].kind == 0 && cat[s].pal) || is_small(s); };
-        auto zone_of_side = [&](int64_t s, int side) -> int32_t {
-            const int kind = side ? d->back_kind[s] : d->front_kind[s];
-            return kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
-        };
-        std::vector<int32_t> uf(Z);
-        std::iota(uf.begin(), uf.end(), 0);
-        auto find = [&](int32_t x) {
-            while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; }
-            return x;
-        };
-        for (int64_t s = 0; s < S; s++) {
-            const int32_t zf = zone_of_side(s, 0), zb = zone_of_side(s, 1);
-            if (zf >= 0 && zb >= 0) {
-                const int32_t a = find(zf), c = find(zb);
-                if (a != c) uf[std::max(a, c)] = std::min(a, c);
-            }
-        }
-        // per cluster (root zone): its surfaces (CSR), whether all of them are fusable
-        std::vector<int64_t> coff(Z + 1, 0);
-        std::vector<uint8_t> cok(Z, 1);
-        auto root_of = [&](int64_t s) -> int32_t {
-            const int32_t zf = zone_of_side(s, 0), zb = zone_of_side(s, 1);
-            return zf >= 0 ? find(zf) : (zb >= 0 ? find(zb) : -1);
-        };
-        std::vector<int32_t> sroot(S);
-        for (int64_t s = 0; s < S; s++) {
-            sroot[s] = root_of(s);
-            if (sroot[s] >= 0) {
-                coff[sroot[s] + 1]++;
-                if (!fusable(s)) cok[sroot[s]] = 0;
-            }
-        }
-        for (int64_t z = 0; z < Z; z++) coff[z + 1] += coff[z];
-        std::vector<int64_t> csurf(Z > 0 ? coff[Z] : 0), ccur(coff.begin(), coff.end() - 1);
-        for (int64_t s = 0; s < S; s++)
-            if (sroot[s] >= 0) csurf[ccur[sroot[s]]++] = s;
-        std::vector<std::vector<int32_t>> czones(Z);  // zones of each root
-        for (int64_t z = 0; z < Z; z++) czones[find((int32_t)z)].push_back((int32_t)z);
-
-        // open workgroup per class: surfaces per k, zones so far
-        struct Open { int blk = -1; int cnt[kWave + 1] = {}; int nsmall = 0; int nz = 0; int ne = 0; };
-        Open open[2 * kNumFast];  // [class][mixed]
-        auto new_block = [&](int cls, bool mixed) {
-            blocks.push_back(BlockPlan{cls, mixed, {}});
-            return (int)blocks.size() - 1;
-        };
-        auto small_tiles = [](int n_small) { return (n_small + kWave - 1) / kWave; };
-        // Cost model (measured on MI355X, profiles/README.md): what the cluster-resident march of a cluster costs by
-        // blocking factor and tile count (below) against what streaming it costs — its algorithmic bytes at the
-        // ~5.5 TB/s the streamed kernels sustain, plus k_zones' share. The cheapest blocking factor is taken.
-        constexpr double kStreamBytesPerNs = 5500.0, kZoneNs = 1.8;
-        // ns per cluster and sub-timestep. Up to four tiles (two or three workgroups per compute unit): per tile —
-        // 16 nodes per lane 2.05 (1 M x 32: 82 us / 40 000 tiles), 8: 1.8 (1 M x 13: 72 us), 4: 1.15 (1 M x 8: 46 us).
-        // Five to eight tiles (a workgroup has a compute unit to itself, however many of its wavefronts work): per
-        // workgroup — 16: 16.5 (1 M x 48: 165 us / 10 000), 8: 14.8 (1 M x 32: 148 us), 4: 12 (1 M x 10: 118 us).
-        auto cluster_ns = [](int m, int tiles) {
-            if (tiles <= 4) return tiles * (m == 16 ? 2.05 : (m == 8 ? 1.8 : 1.15));
-            return m == 16 ? 16.5 : (m == 8 ? 14.8 : 12.0);
-        };
-        auto tile_ns = [](int m) { return m == 16 ? 2.05 : (m == 8 ? 1.8 : 1.15); };  // (surfaces that face no zone)
-        auto fused_cost = [&](int n, int m) {  // (explicit nodes_per_lane, lone surfaces: lanes of the surface)
-            return (double)((n + m - 1) / m);
-        };
-        const int ms_all[3] = {4, 8, 16};
-        for (int64_t r = 0; r < Z; r++) {
-            if (find((int32_t)r) != r || !cok[r] || coff[r + 1] == coff[r]) continue;
-            // one blocking factor for the cluster: the cheapest that keeps every surface at two lanes or more
-            // (gas cavities: 4 or 8 nodes per lane only — the 16-node cavity variant does not fit the registers)
-            // Small all-no-mass surfaces (glazing, thin walls) of the cluster get wavefronts of their own in the
-            // workgroup (one lane per surface); such a "mixed" workgroup runs the universal kernel variant of its
-            // blocking factor: no-mass facings allowed, gas cavities allowed (up to 8 nodes per lane).
-            bool any_cav = false;
-            int n_small = 0;
-            for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
-                if (is_small(csurf[q])) n_small++;
-                else any_cav = any_cav || cat[csurf[q]].ncav > 0;
-            }
-            const bool mixed = n_small > 0;
-            int M = opt.nodes_per_lane;
-            if (M == 16 && any_cav) continue;  // streamed
-            if (M == 0) {
-                double best_cost = 0.0;
-                for (int m : ms_all) {  // cheapest tiles win; on a tie the larger lanes
-                    if (m == 16 && any_cav) continue;
-                    int c_k[kWave + 1] = {};
-                    bool ok = true;
-                    for (int64_t q = coff[r]; q < coff[r + 1] && ok; q++) {
-                        if (is_small(csurf[q])) continue;
-                        const int kk = (placed[csurf[q]].n + m - 1) / m;
-                        ok = kk >= 2 && kk <= kWave;
-                        if (ok) c_k[kk]++;
-                    }
-                    if (!ok) continue;
-                    const int nt_m = tiles_needed(c_k) + small_tiles(n_small);
-                    if (nt_m > kFusedMaxWaves) continue;
-                    const double t = cluster_ns(m, nt_m);
-                    if (M == 0 || t <= best_cost) { M = m; best_cost = t; }
-                }
-                if (M == 0) M = 4;
-            }
-            int nm = 0, cnt[kWave + 1] = {}, ne = 0;
-            bool fits = true;
-            for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
-                const Placed &pl = placed[csurf[q]];
-                ne += (zone_of_side(csurf[q], 0) >= 0) + (zone_of_side(csurf[q], 1) >= 0);
-                if (is_small(csurf[q])) continue;
-                const int k = (pl.n + M - 1) / M;
-                if (k > kWave || k < 2) { fits = false; break; }  // (the fused kernels have no single-lane path)
-                cnt[k]++;
-                nm |= cat[csurf[q]].nm;
-            }
-            const int nz = (int)czones[r].size();
-            if (!fits || tiles_needed(cnt) + small_tiles(n_small) > kFusedMaxWaves || nz > kFusedMaxZones ||
-                ne > kFusedMaxEntries)
-                continue;  // streamed
-            if (!fuse_always) {
-                // No glazing in a fused workgroup: a window's no-mass loop re-evaluates its gas cavity every pass
-                // (surface.rs:814) — a long serial chain the whole workgroup would wait for at every sub-timestep's
-                // barrier (rooms with double glazing: 8x slower fused than streamed). Otherwise: tiles against bytes.
-                int n_cav_small = 0;
-                double bytes = 0.0;
-                for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
-                    n_cav_small += cat[csurf[q]].kind == kSmallCav;
-                    bytes += 32.0 * placed[csurf[q]].n + 152.0;
-                }
-                const int tiles = tiles_needed(cnt) + small_tiles(n_small);
-                // A small batch is bound by launches and latency, not by throughput: there the resident march wins
-                // with any blocking factor (one launch per march call instead of two or more per sub-timestep).
-                const bool small_batch = S <= 8192;
-                if (n_cav_small > 0 || tiles == 0) continue;                                        // streamed
-                if (!small_batch && cluster_ns(M, tiles) > 0.85 * (bytes / kStreamBytesPerNs + kZoneNs * nz))
-                    continue;                                                                       // streamed
-            }
-            Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1};
-            const int cls = fast_class(M, cc);
-            Open &o = open[2 * cls + (mixed ? 1 : 0)];
-            int merged[kWave + 1];
-            for (int k = 0; k <= kWave; k++) merged[k] = o.cnt[k] + cnt[k];
-            // Workgroups of four tiles are the target (two of them share a compute unit, so one's zone balance —
-            // a short serial section — overlaps the other's stencil work): clusters are merged only up to four
-            // tiles; a cluster that needs five to eight gets a workgroup of its own.
-            if (o.blk < 0 || tiles_needed(merged) + small_tiles(o.nsmall + n_small) > 4 || o.nz + nz > kFusedMaxZones ||
-                o.ne + ne > kFusedMaxEntries) {
-                o = Open();
-                o.blk = new_block(cls, mixed);
-                for (int k = 0; k <= kWave; k++) merged[k] = cnt[k];
-            }
-            for (int k = 0; k <= kWave; k++) o.cnt[k] = merged[k];
-            o.nsmall += n_small;
-            o.nz += nz;
-            o.ne += ne;
-            for (int32_t z : czones[r]) blocks[o.blk].zones.push_back(z);
-            for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
-                Placed &pl = placed[csurf[q]];
-                pl.blk = o.blk;
-                if (is_small(csurf[q])) {
-                    pl.cls = kSmallCav;  // (one kind of small tile inside workgroups: the cavity variant covers both)
-                } else {
-                    pl.cls = cls;
-                    pl.k = (pl.n + M - 1) / M;
-                }
-            }
-        }
-        // surfaces that face no zone: any grouping will do; workgroups of up to 4 tiles of equal k
-        std::vector<int64_t> lone;
-        std::vector<uint8_t> lone_ok(S, 1);
-        for (int64_t s = 0; s < S; s++)
-            if (sroot[s] < 0 && fusable(s) && !is_small(s)) lone.push_back(s);
-        for (int64_t s : lone) {
-            Placed &pl = placed[s];
-            int M = opt.nodes_per_lane;
-            const bool cav = cat[s].ncav > 0;
-            if (M == 0) {
-                M = 4;
-                for (int m : {8, 16})
-                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
-            }
-            int k = (pl.n + M - 1) / M;
-            const bool gains = tile_ns(M) * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
-            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
-            pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
-            pl.k = k;
-        }
-        std::stable_sort(lone.begin(), lone.end(), [&](int64_t x, int64_t y) {
-            if (placed[x].cls != placed[y].cls) return placed[x].cls < placed[y].cls;
-            return placed[x].k < placed[y].k;
-        });
-        {
-            int cur_cls = -1, cur_k = -1, cur_blk = -1, in_blk = 0;
-            for (int64_t s : lone) {
-                Placed &pl = placed[s];
-                if (!lone_ok[s] || pl.cls >= kNumFast) continue;
-                const int cap = 4 * (kWave / pl.k);
-                if (pl.cls != cur_cls || pl.k != cur_k || in_blk >= cap) {
-                    cur_cls = pl.cls; cur_k = pl.k; in_blk = 0;
-                    cur_blk = new_block(pl.cls, false);
-                }
-                pl.blk = cur_blk;
-                in_blk++;
-            }
-        }
-    }
-    if (fuse && !fuse_always && !blocks.empty()) {
-        // Fusing part of a batch does not pay: the streamed remainder still pays its launches and latencies every
-        // sub-timestep, and the two kinds of kernels share the chip badly (measured: 2 000 clustered walls with 733
-        // of them fused 89 us per sub-timestep against 64 all streamed; 1 M clustered walls with 205 000 fused 260
-        // against 222). A small batch is fused only as a whole, a large one when at least nine tenths of its nodes are.
-        double fused_nodes = 0.0, all_nodes = 0.0;
-        bool remainder = false;
-        for (int64_t s = 0; s < S; s++) {
-            all_nodes += placed[s].n;
-            if (placed[s].blk >= 0) fused_nodes += placed[s].n;
-            else remainder = true;
-        }
-        if (S <= 8192 ? remainder : fused_nodes < 0.9 * all_nodes) {
-            placed = placed_streamed;
-            blocks.clear();
-        }
-    }
-    for (int64_t s = 0; s < S; s++) {
-        const int cls = placed[s].cls;
-        b->class_counts[cls < kNumFast ? cls / 6 : (cls < kGeneral ? 3 : 4)]++;
-        if (cls < kNumFast && kFastPAL[cls]) b->n_palette++;
-        if (placed[s].blk >= 0) b->n_fused_surfaces++;
-    }
-
-    // ---- order: class, then streamed surfaces before the fused workgroups, then lanes per surface ----
-    // Small surfaces with a gas cavity are grouped by the branch of the Nusselt correlation their tilt selects
-    // (gas.rs:197-315: five ranges of the cavity angle): the lanes of a wavefront then take the same branch instead of
-    // the wavefront running all of them one after the other.
-    std::vector<uint8_t> tilt_key(S, 0);
-    if (d->seg_cavity && d->n_cavities > 0)
-        for (int64_t s = 0; s < S; s++) {
-            if (placed[s].cls != kSmallCav && !(placed[s].cls < kNumFast && kFastCAV[placed[s].cls])) continue;
-            const int64_t o = d->node_offset[s];
-            for (int i = 0; i < placed[s].n; i++)
-                if (d->seg_cavity[o + i] >= 0) {
-                    double g = std::fmod(d->cavities[d->seg_cavity[o + i]].angle, 3.14159265358979323846);
-                    if (g > 1.5707963267948966) g = 3.14159265358979323846 - g;  // the kernel flips the angle by the sign of dT
-                    const double deg = g * (180.0 / 3.14159265358979323846);
-                    tilt_key[s] = deg < 59.5 ? 0 : (deg < 60.5 ? 1 : (deg < 89.5 ? 2 : 3));
-                    break;
-                }
-        }
-    std::vector<int64_t> order(S);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-        const Placed &a = placed[x], &c = placed[y];
-        if (a.cls != c.cls) return a.cls < c.cls;
-        if (a.blk != c.blk) return a.blk < c.blk;
-        if (a.cls < kNumFast && a.k != c.k) return a.k < c.k;
-        if (tilt_key[x] != tilt_key[y]) return tilt_key[x] < tilt_key[y];
-        if (a.cls < kNumFast) return false;
-        return a.n < c.n;
-    });
-
-    // ---- tiles ----
-    std::vector<FastTile> fast_tiles[kNumFast];
-    std::vector<GeneralTile> gen_tiles;
-    std::vector<int64_t> dev_of(S);            // original -> device surface
-    std::vector<int64_t> node0_index(S), nodeN_index(S);  // index of first / last node in the T buffer
-    std::vector<int64_t> orig_of(S);
-    int64_t node_cursor = 0, scratch_cursor = 0;
-    int64_t dcur = 0;
-    size_t pos = 0;
-    struct NodeMap { int64_t base; int Lk; int k; int M; int g; int tile; };  // per device surface
-    std::vector<int> blk_first_tile(blocks.size(), -1), blk_n_tiles(blocks.size(), 0);
-    std::vector<int> blk_first_small(blocks.size(), -1), blk_n_small(blocks.size(), 0);
-    std::vector<NodeMap> nmap(S);
-    int prev_cls = -1;
-    while (pos < (size_t)S) {
-        const Placed &p0 = placed[order[pos]];
-        if (p0.cls != prev_cls) node_cursor = (node_cursor + 15) / 16 * 16;  // class bytes are loaded 4/8/16 at a time
-        prev_cls = p0.cls;
-        if (p0.cls < kNumFast) {
-            const int M = kFastM[p0.cls], k = p0.k;
-            const int Gmax = kWave / k, Lk = Gmax * k;
-            size_t end = pos;
-            while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].k == k &&
-                   placed[order[end]].blk == p0.blk && (int)(end - pos) < Gmax)
-                end++;
-            bool all_full = true;
-            for (size_t q = pos; q < end; q++) all_full = all_full && (placed[order[q]].n == k * M);
-            FastTile t;
-            t.node_base = node_cursor;
-            t.surf_base = (int32_t)dcur;
-            t.k = (int16_t)(k | (all_full ? 0x100 : 0));
-            t.G = (int16_t)(end - pos);
-            const int tile_index = (int)fast_tiles[p0.cls].size();
-            fast_tiles[p0.cls].push_back(t);
-            if (p0.blk >= 0) {
-                if (blk_first_tile[p0.blk] < 0) blk_first_tile[p0.blk] = tile_index;
-                blk_n_tiles[p0.blk]++;
-            } else {
-                b->n_stream_tiles[p0.cls] = tile_index + 1;  // streamed tiles come first in every class
-            }
-            for (size_t q = pos; q < end; q++) {
-                const int64_t s = order[q];
-                dev_of[s] = dcur;
-                orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, Lk, k, M, (int)(q - pos), tile_index};
-                dcur++;
-            }
-            node_cursor += (int64_t)M * Lk;
-            pos = end;
-        } else {
-            if (gen_tiles.empty()) b->gen_base = node_cursor;
-            size_t end = pos;
-            while (end < (size_t)S && end < pos + (size_t)kWave && placed[order[end]].cls == p0.cls &&
-                   placed[order[end]].blk == p0.blk)
-                end++;
-            if (p0.cls < kGeneral) b->n_small_tiles++;
-            if (p0.cls == kSmall) b->n_small_plain_tiles++;
-            if (p0.cls == kSmallCav && p0.blk < 0) b->n_smallcav_stream_tiles++;
-            if (p0.blk >= 0) {
-                if (blk_first_small[p0.blk] < 0) blk_first_small[p0.blk] = (int)gen_tiles.size();
-                blk_n_small[p0.blk]++;
-            }
-            int n_max = 0;
-            for (size_t q = pos; q < end; q++) n_max = std::max(n_max, placed[order[q]].n);
-            GeneralTile t;
-            t.node_base = node_cursor;
-            t.surf_base = (int32_t)dcur;
-            t.G = (int32_t)(end - pos);
-            t.n_max = n_max;
-            t.pad = 0;
-            t.scratch_base = scratch_cursor;
-            gen_tiles.push_back(t);
-            for (size_t q = pos; q < end; q++) {
-                const int64_t s = order[q];
-                dev_of[s] = dcur;
-                orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos), (int)gen_tiles.size() - 1};
-                dcur++;
-            }
-            node_cursor += (int64_t)n_max * kWave;
-            scratch_cursor += (int64_t)kScratchArrays * n_max * kWave;
-            pos = end;
-        }
-    }
-    if (gen_tiles.empty()) b->gen_base = node_cursor;
-    b->node_slots = node_cursor;
-    if (node_cursor >= (int64_t)1 << 32) return fail(HEAT_E_SIZE, "batch too large: %lld node slots", (long long)node_cursor);
-
-    auto node_index = [&](int64_t dsurf, int i) -> int64_t {
-        const NodeMap &m = nmap[dsurf];
-        if (m.M == 0) return m.base + (int64_t)i * kWave + m.g;
-        const int lane = m.g * m.k + i / m.M, j = i % m.M;
-        return m.base + ((int64_t)(j >> 1) * m.Lk + lane) * 2 + (j & 1);
-    };
-
-    // ---- per-node constants ----
-    std::vector<double> hV(node_cursor, 0.0), hU(node_cursor, 0.0);
-    std::vector<uint8_t> hCls(b->n_palette ? node_cursor : 0, 0);
-    std::vector<double> hPal(b->n_palette ? (size_t)S * kPal : 0, 0.0);
-    const int64_t gen_slots = node_cursor - b->gen_base;
-    std::vector<double> hAf(gen_slots, 0.0), hAb(gen_slots, 0.0), hMass(gen_slots, 0.0);
-    std::vector<int32_t> hCav(gen_slots, -1);
-    for (int64_t dd = 0; dd < S; dd++) {
-        const int64_t s = orig_of[dd];
-        const int64_t o = d->node_offset[s];
-        const int n = placed[s].n;
-        const bool gen = placed[s].cls >= kNumFast;
-        const bool pal = !gen && kFastPAL[placed[s].cls];
-        int nv = 1, nu = 1;
-        double *pp = pal ? &hPal[(size_t)dd * kPal] : nullptr;
-        for (int i = 0; i < n; i++) {
-            const int64_t idx = node_index(dd, i);
-            const double mass = d->mass[o + i];
-            hV[idx] = (mass >= kMassThreshold) ? d->dt / mass : 0.0;  // dt / C, surface.rs:172
-            const bool cav = d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0;
-            hU[idx] = cav ? 0.0 : d->uvalue[o + i];
-            if (pal) {
-                int vc = -1, uc = -1;
-                for (int q = 0; q < nv; q++) if (pp[q] == hV[idx]) vc = q;
-                if (vc < 0) { vc = nv; pp[nv++] = hV[idx]; }
-                for (int q = 0; q < nu; q++) if (pp[kPalV + q] == hU[idx]) uc = q;
-                if (uc < 0) { uc = nu; pp[kPalV + nu++] = hU[idx]; }
-                const NodeMap &m = nmap[dd];
-                const int lane = m.g * m.k + i / m.M, j = i % m.M;
-                hCls[m.base + (int64_t)lane * m.M + j] = (uint8_t)(vc | (uc << 3));
-            }
-            if (gen) {
-                const int64_t gi = idx - b->gen_base;
-                hAf[gi] = d->front_alpha[o + i];
-                hAb[gi] = d->back_alpha[o + i];
-                hMass[gi] = mass;
-                hCav[gi] = cav ? d->seg_cavity[o + i] : -1;
-            }
-        }
-        node0_index[s] = node_index(dd, 0);
-        nodeN_index[s] = node_index(dd, n - 1);
-    }
-
-    // ---- cavity references of the CAV fast classes ----
-    std::vector<int32_t> hCavRef;
-    {
-        bool any = false;
-        for (int64_t s = 0; s < S; s++) any = any || (placed[s].cls < kNumFast && kFastCAV[placed[s].cls]);
-        if (any) {
-            hCavRef.assign((size_t)4 * S, -1);
-            for (int64_t dd = 0; dd < S; dd++) {
-                const int64_t s = orig_of[dd];
-                if (!(placed[s].cls < kNumFast && kFastCAV[placed[s].cls])) continue;
-                const int64_t o = d->node_offset[s];
-                int r = 0;
-                for (int i = 0; i < placed[s].n && r < 2 && d->seg_cavity && d->n_cavities > 0; i++)
-                    if (d->seg_cavity[o + i] >= 0) {
-                        hCavRef[4 * dd + 2 * r] = i;
-                        hCavRef[4 * dd + 2 * r + 1] = d->seg_cavity[o + i];
-                        r++;
-                    }
-            }
-        }
-    }
-
-    // ---- per-side records (device order) ----
-    std::vector<int32_t> hMeta(S);
-    std::vector<SideConst> hSide(2 * S);
-    std::vector<double> hAlpha(2 * S, 1.0);
-    std::vector<double> hFix;
-    std::vector<int64_t> hFirst(S), hSlots(8 * S);
-    const bool has_fix = d->front_hs_fix != nullptr;
-    if (has_fix) hFix.resize(2 * S);
-    for (int64_t dd = 0; dd < S; dd++) {
-        const int64_t s = orig_of[dd];
-        const int64_t o = d->node_offset[s];
-        const int n = placed[s].n;
-        hMeta[dd] = n;
-        const double cos_tilt = d->cos_tilt[s];
-        // is_windward: only tilted surfaces test the wind direction (surface.rs:38)
-        const int always_windward = (std::fabs(cos_tilt) < 0.98) ? 0 : 4;
-        // forced convection: 2.537 * Wf * Rf * sqrt(P * V_z / A), Rf = COEFFICIENTS[1] = 1.67, V_z = wind * modifier
-        // (convection.rs:151-168; surface.rs:646,691). Wf and sqrt(wind) are applied per sub-timestep.
-        const double forced = 2.537 * 1.67 * std::sqrt(d->perimeter[s] * d->wind_modifier[s] / d->area[s]);
-        for (int side = 0; side < 2; side++) {
-            SideConst c;
-            const int kind = side ? d->back_kind[s] : d->front_kind[s];
-            c.kind_n = kind | always_windward | (n << 16);
-            c.zone = kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : 0;
-            c.ambient = side ? d->back_ambient[s] : d->front_ambient[s];
-            c.emis = side ? d->back_emissivity[s] : d->front_emissivity[s];
-            c.alpha = side ? d->back_alpha[o + n - 1] : d->front_alpha[o];
-            // front Outdoor flips the sign (surface.rs:652); back Outdoor does not (surface.rs:689-696)
-            c.cos_eff = (side == 0 && kind == HEAT_BOUNDARY_OUTDOOR) ? -cos_tilt : cos_tilt;
-            hAlpha[(int64_t)side * S + dd] = 1.0;
-            if (placed[s].cls < kNumFast) {
-                // fast classes: the absorptance goes into SideDyn::solar at upload; the two slots carry the TARP
-                // natural-convection coefficients of convection.rs:87-110 with the tilt-dependent division done here
-                hAlpha[(int64_t)side * S + dd] = c.alpha;
-                const double ce = c.cos_eff, act = std::fabs(ce);
-                const double up = 9.482 / (7.238 - act), down = 1.81 / (1.382 + act);
-                double pos, neg;  // air warmer / colder than the surface
-                if (ce != ce) { pos = neg = ce; }
-                else if (act < 1e-3) { pos = neg = 1.31; }
-                else if (ce > 0.) { pos = up; neg = down; }
-                else { pos = down; neg = up; }
-                c.cos_eff = pos;
-                c.alpha = neg;
-            }
-            c.forced = kind == HEAT_BOUNDARY_OUTDOOR ? forced : 0.0;
-            c.nx = d->normal_x[s];
-            c.ny = d->normal_y[s];
-            hSide[(int64_t)side * S + dd] = c;
-            if (has_fix) hFix[(int64_t)side * S + dd] = side ? d->back_hs_fix[s] : d->front_hs_fix[s];
-        }
-        hFirst[dd] = d->first_node_slot[s];
-        const int64_t *src[8] = {d->hs_front_slot, d->hs_back_slot, d->flow_front_slot, d->flow_back_slot,
-                                 d->solar_front_slot, d->solar_back_slot, d->ir_front_slot, d->ir_back_slot};
-        for (int a = 0; a < 8; a++) hSlots[(int64_t)a * S + dd] = src[a][s];
-    }
-
-    // ---- zone contribution lists, in the reference's order (model.rs:562-585) ----
-    std::vector<int64_t> zoff(Z + 1, 0);
-    for (int64_t s = 0; s < S; s++) {
-        if (d->front_kind[s] == HEAT_BOUNDARY_SPACE) zoff[d->front_zone[s] + 1]++;
-        if (d->back_kind[s] == HEAT_BOUNDARY_SPACE) zoff[d->back_zone[s] + 1]++;
-    }
-    for (int64_t z = 0; z < Z; z++) zoff[z + 1] += zoff[z];
-    std::vector<ZoneEntry> zent(Z > 0 ? zoff[Z] : 0);
-    {
-        std::vector<int64_t> cur(zoff.begin(), zoff.end() - (Z >= 0 ? 1 : 0));
-        for (int64_t s = 0; s < S; s++) {
-            if (d->front_kind[s] == HEAT_BOUNDARY_SPACE) {
-                ZoneEntry e{(uint32_t)node0_index[s], (uint32_t)dev_of[s], d->area[s]};
-                zent[cur[d->front_zone[s]]++] = e;
-            }
-            if (d->back_kind[s] == HEAT_BOUNDARY_SPACE) {
-                ZoneEntry e{(uint32_t)nodeN_index[s], (uint32_t)(S + dev_of[s]), d->area[s]};
-                zent[cur[d->back_zone[s]]++] = e;
-            }
-        }
-    }
-
-    // ---- cluster-resident march: workgroup tables ----
-    std::vector<int32_t> fz, fz_eoff(1, 0);
-    std::vector<uint16_t> fent;
-    std::vector<double> side_area(2 * S, 0.0);
-    std::vector<int16_t> side_lz(2 * S, -1);
-    b->h_zone_block.assign(Z, -1);
-    b->any_fused = false;
-    if (!blocks.empty()) {
-        std::vector<int32_t> lz_of_zone(Z, -1);
-        std::vector<int> blk_fw(blocks.size(), 4);
-        std::vector<int32_t> blk_first_zone(blocks.size(), 0);
-        for (size_t bi = 0; bi < blocks.size(); bi++) {
-            if (blk_n_tiles[bi] + blk_n_small[bi] <= 0) continue;  // (an empty plan: cannot happen, kept harmless)
-            blk_fw[bi] = blk_n_tiles[bi] + blk_n_small[bi] <= 4 ? 4 : 8;
-            blk_first_zone[bi] = (int32_t)fz.size();
-            for (size_t j = 0; j < blocks[bi].zones.size(); j++) {
-                const int32_t z = blocks[bi].zones[j];
-                lz_of_zone[z] = (int32_t)j;
-                b->h_zone_block[z] = (int32_t)bi;
-                fz.push_back(z);
-            }
-        }
-        // contributions in the reference's order inside each zone (model.rs:562-585): counting sort by fused zone
-        std::vector<int32_t> fz_index(Z, -1);
-        for (size_t i = 0; i < fz.size(); i++) fz_index[fz[i]] = (int32_t)i;
-        std::vector<int32_t> cnt(fz.size() + 1, 0);
-        auto side_zone = [&](int64_t s, int side) -> int32_t {
-            const int kind = side ? d->back_kind[s] : d->front_kind[s];
-            const int32_t z = kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
-            return (z >= 0 && placed[s].blk >= 0) ? z : -1;
-        };
-        for (int64_t s = 0; s < S; s++)
-            for (int side = 0; side < 2; side++) {
-                const int32_t z = side_zone(s, side);
-                if (z >= 0) cnt[fz_index[z] + 1]++;
-            }
-        for (size_t i = 0; i < fz.size(); i++) cnt[i + 1] += cnt[i];
-        fz_eoff.assign(cnt.begin(), cnt.end());
-        fent.resize(cnt[fz.size()]);
-        std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int64_t s = 0; s < S; s++)
-            for (int side = 0; side < 2; side++) {
-                const int32_t z = side_zone(s, side);
-                if (z < 0) continue;
-                const int bi = placed[s].blk;
-                const NodeMap &m = nmap[dev_of[s]];
-                // fast-path surfaces: the first / last lane of the surface owns the side; small surfaces: their lane
-                const int lane = (m.M == 0) ? m.g : (side ? (m.g * m.k + m.k - 1) : (m.g * m.k));
-                const int wave_in_block = (m.M == 0) ? blk_n_tiles[bi] + (m.tile - blk_first_small[bi])
-                                                     : (m.tile - blk_first_tile[bi]);
-                const uint32_t slot = (uint32_t)(side * kWave * blk_fw[bi] + wave_in_block * kWave + lane);
-                fent[cur[fz_index[z]]++] = (uint16_t)slot;
-                side_lz[(int64_t)side * S + dev_of[s]] = (int16_t)lz_of_zone[z];
-            }
-        for (size_t bi = 0; bi < blocks.size(); bi++) {
-            if (blk_n_tiles[bi] + blk_n_small[bi] <= 0) continue;
-            FusedBlock fb{std::max(blk_first_tile[bi], 0), blk_n_tiles[bi], blk_first_zone[bi],
-                          (int32_t)blocks[bi].zones.size(), std::max(blk_first_small[bi], 0), blk_n_small[bi]};
-            b->h_fblocks[blocks[bi].cls][(blk_fw[bi] == 4 ? 0 : 1) + (blocks[bi].mixed ? 2 : 0)].push_back(fb);
-            b->any_fused = true;
-        }
-    }
+    b->n_state = p.n_state;
+    b->n_cav = p.n_cav;
+    b->dt = p.dt;
+    b->n_nodes = p.n_nodes;
+    b->algorithmic_bytes = p.algorithmic_bytes;
+    for (int i = 0; i < 5; i++) b->class_counts[i] = p.class_counts[i];
+    b->n_palette = p.n_palette;
+    b->n_fused_surfaces = p.n_fused_surfaces;
+    b->gen_base = p.gen_base;
+    b->node_slots = p.node_slots;
+    b->n_small_tiles = p.n_small_tiles;
+    b->n_small_plain_tiles = p.n_small_plain_tiles;
+    b->n_smallcav_stream_tiles = b->n_smallcav_stream_tiles0 = p.n_smallcav_stream_tiles;
+    b->any_fused = p.any_fused;
+    b->h_zone_block = p.zone_block;
     {
         std::vector<int32_t> sz;
         for (int64_t z = 0; z < Z; z++) if (b->h_zone_block[z] < 0) sz.push_back((int32_t)z);
         b->n_stream_zones = (int)sz.size();
         HIP_TRY(b->d_stream_zones.upload(sz));
     }
-    b->h_gen_tiles0 = gen_tiles;
-    b->n_smallcav_stream_tiles0 = b->n_smallcav_stream_tiles;
+    b->h_gen_tiles0 = p.gen_tiles;
     for (int c = 0; c < kNumFast; c++) {
         for (int g2 = 0; g2 < 4; g2++) {
-            HIP_TRY(b->d_fblocks[c][g2].upload(b->h_fblocks[c][g2]));
-            b->h_fblocks0[c][g2] = b->h_fblocks[c][g2];
+            b->h_fblocks[c][g2] = b->h_fblocks0[c][g2] = p.fblocks[c][g2];
+            HIP_TRY(b->d_fblocks[c][g2].upload(p.fblocks[c][g2]));
         }
-        b->h_tiles0[c] = fast_tiles[c];
-        b->n_stream_tiles0[c] = b->n_stream_tiles[c];
+        b->h_tiles0[c] = p.fast_tiles[c];
+        b->n_stream_tiles[c] = b->n_stream_tiles0[c] = p.n_stream_tiles[c];
+        b->n_fast_tiles[c] = (int)p.fast_tiles[c].size();
+        HIP_TRY(b->d_fast_tiles[c].upload(p.fast_tiles[c]));
+        b->nm_count_base[c] = p.nm_count_base[c];
     }
-    b->h_fzones = fz;
-    HIP_TRY(b->d_fzones.upload(fz));
-    HIP_TRY(b->d_fzone_eoff.upload(fz_eoff));
-    for (int64_t dd = 0; dd < S; dd++) side_area[dd] = side_area[S + dd] = d->area[orig_of[dd]];
-    HIP_TRY(b->d_fslots.upload(fent));
-    HIP_TRY(b->d_side_area.upload(side_area));
-    HIP_TRY(b->d_side_lzone.upload(side_lz));
-
-    // zones this batch's surfaces touch (for sharded batches)
-    b->h_touched.assign(Z, 0);
-    for (int64_t z = 0; z < Z; z++) b->h_touched[z] = zoff[z + 1] > zoff[z] ? 1 : 0;
+    b->nm_count_base[kNumFast] = p.nm_count_base[kNumFast];
+    b->h_fzones = p.fzones;
+    HIP_TRY(b->d_fzones.upload(p.fzones));
+    HIP_TRY(b->d_fzone_eoff.upload(p.fzone_eoff));
+    HIP_TRY(b->d_fslots.upload(p.fslots));
+    HIP_TRY(b->d_side_area.upload(p.side_area));
+    HIP_TRY(b->d_side_lzone.upload(p.side_lzone));
+    b->h_touched = p.touched;
 
     // ---- host copies used by download ----
-    b->h_first_slot.assign(d->first_node_slot, d->first_node_slot + S);
-    b->h_node_count.resize(S);
-    for (int64_t s = 0; s < S; s++) b->h_node_count[s] = placed[s].n;
-    b->h_out_slots[0].assign(d->hs_front_slot, d->hs_front_slot + S);
-    b->h_out_slots[1].assign(d->hs_back_slot, d->hs_back_slot + S);
-    b->h_out_slots[2].assign(d->flow_front_slot, d->flow_front_slot + S);
-    b->h_out_slots[3].assign(d->flow_back_slot, d->flow_back_slot + S);
-    if (Z > 0) b->h_zone_slot_h.assign(d->zone_slot, d->zone_slot + Z);
+    b->h_first_slot = std::move(p.h_first_slot);
+    b->h_node_count = std::move(p.h_node_count);
+    for (int a = 0; a < 4; a++) b->h_out_slots[a] = std::move(p.h_out_slots[a]);
+    b->h_zone_slot_h = p.zone_slot;
 
     // ---- upload ----
-    for (int c = 0; c < kNumFast; c++) {
-        b->n_fast_tiles[c] = (int)fast_tiles[c].size();
-        HIP_TRY(b->d_fast_tiles[c].upload(fast_tiles[c]));
-    }
-    b->n_gen_tiles = (int)gen_tiles.size();
-    HIP_TRY(b->d_gen_tiles.upload(gen_tiles));
-    HIP_TRY(b->d_T.zeros(node_cursor));
-    HIP_TRY(b->d_V.upload(hV));
-    HIP_TRY(b->d_U.upload(hU));
-    HIP_TRY(b->d_alpha_f.upload(hAf));
-    HIP_TRY(b->d_alpha_b.upload(hAb));
-    HIP_TRY(b->d_mass.upload(hMass));
-    HIP_TRY(b->d_cav_idx.upload(hCav));
-    HIP_TRY(b->d_cavref.upload(hCavRef));
-    HIP_TRY(b->d_cls.upload(hCls));
-    HIP_TRY(b->d_pal.upload(hPal));
-    HIP_TRY(b->d_scratch.alloc(scratch_cursor));
-    {
-        std::vector<CavityDev> hc(d->n_cavities);
-        for (int64_t c = 0; c < d->n_cavities; c++) {
-            const heat_cavity &x = d->cavities[c];
-            if (x.gas < 0 || x.gas > 3) return fail(HEAT_E_INVALID_ARG, "cavity %lld: unknown gas", (long long)c);
-            hc[c] = CavityDev{x.thickness, x.height, x.angle, x.eout, x.ein, x.gas, 0};
-        }
-        HIP_TRY(b->d_cavs.upload(hc));
-    }
-    HIP_TRY(b->d_meta.upload(hMeta));
-    HIP_TRY(b->d_side_const.upload(hSide));
-    HIP_TRY(b->d_side_alpha.upload(hAlpha));
-    if (has_fix) HIP_TRY(b->d_hs_fix.upload(hFix));
+    b->n_gen_tiles = (int)p.gen_tiles.size();
+    HIP_TRY(b->d_gen_tiles.upload(p.gen_tiles));
+    HIP_TRY(b->d_T.zeros(p.node_slots));
+    HIP_TRY(b->d_V.upload(p.V));
+    HIP_TRY(b->d_U.upload(p.U));
+    HIP_TRY(b->d_alpha_f.upload(p.alpha_f));
+    HIP_TRY(b->d_alpha_b.upload(p.alpha_b));
+    HIP_TRY(b->d_mass.upload(p.mass));
+    HIP_TRY(b->d_cav_idx.upload(p.cav_idx));
+    HIP_TRY(b->d_cavref.upload(p.cavref));
+    HIP_TRY(b->d_cls.upload(p.cls));
+    HIP_TRY(b->d_pal.upload(p.pal));
+    HIP_TRY(b->d_scratch.alloc(p.scratch_slots));
+    HIP_TRY(b->d_cavs.upload(p.cavs));
+    HIP_TRY(b->d_meta.upload(p.meta));
+    HIP_TRY(b->d_side_const.upload(p.side));
+    HIP_TRY(b->d_side_alpha.upload(p.side_alpha));
+    const bool has_fix = !p.hs_fix.empty();
+    if (has_fix) HIP_TRY(b->d_hs_fix.upload(p.hs_fix));
     HIP_TRY(b->d_side_dyn.zeros(2 * S));
     HIP_TRY(b->d_side_out.zeros(2 * S));
-    HIP_TRY(b->d_first_slot.upload(hFirst));
-    HIP_TRY(b->d_slots.upload(hSlots));
-    {
-        std::vector<int64_t> zs(Z);
-        std::vector<double> zv(Z);
-        for (int64_t z = 0; z < Z; z++) { zs[z] = d->zone_slot[z]; zv[z] = d->zone_volume[z]; }
-        HIP_TRY(b->d_zone_slot.upload(zs));
-        HIP_TRY(b->d_zone_vol.upload(zv));
-    }
-    HIP_TRY(b->d_zone_off.upload(zoff));
-    HIP_TRY(b->d_zone_entries.upload(zent));
+    HIP_TRY(b->d_first_slot.upload(p.first_slot));
+    HIP_TRY(b->d_slots.upload(p.slots));
+    HIP_TRY(b->d_zone_slot.upload(p.zone_slot));
+    HIP_TRY(b->d_zone_vol.upload(p.zone_vol));
+    HIP_TRY(b->d_zone_off.upload(p.zone_off));
+    HIP_TRY(b->d_zone_entries.upload(p.zone_entries));
+    HIP_TRY(b->d_zone_contrib.zeros(p.zone_entries.size()));
     HIP_TRY(b->d_zone_T.zeros(Z));
     HIP_TRY(b->d_zone_a0.zeros(Z));
     HIP_TRY(b->d_zone_b0.zeros(Z));
     HIP_TRY(b->d_partial.zeros(2 * Z));
     b->partial_ptr = b->d_partial.p;
-    HIP_TRY(b->d_state.zeros(d->n_state));
+    HIP_TRY(b->d_state.zeros(p.n_state));
     HIP_TRY(b->d_step.zeros(1));
     HIP_TRY(b->d_flags.zeros(1));
-    {   // no-mass pass counters: one slot per tile of the NM fast classes, one per lane of the general-layout tiles
-        size_t n = 0;
-        for (int c = 0; c < kNumFast; c++) {
-            b->nm_count_base[c] = n;
-            if (kFastNM[c]) n += fast_tiles[c].size();
-        }
-        b->nm_count_base[kNumFast] = n;
-        n += gen_tiles.size() * (size_t)kWave;
-        HIP_TRY(b->d_nomass_iters.zeros(std::max<size_t>(n, 1)));
-    }
+    HIP_TRY(b->d_nomass_iters.zeros(p.n_nm_counters));
     if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
 
     // ---- argument bundles ----
@@ -1158,6 +382,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     sa.dyn = b->d_side_dyn.p;
     sa.out = b->d_side_out.p;
     sa.hs_fix = has_fix ? b->d_hs_fix.p : nullptr;
+    sa.zc = b->d_zone_contrib.p;
     sa.S = (int32_t)S;
     sa.pad = 0;
     NodeArrays &na = b->na;
@@ -1192,7 +417,8 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     n_launch += b->n_small_plain_tiles > 0;
     n_launch += n_cav_tiles > 0;
     n_launch += b->n_gen_tiles > b->n_small_tiles;
-    const bool fork = n_launch > 1 && b->side[0] != nullptr;
+    static const bool no_fork = getenv("HEAT_AMD_NO_FORK") != nullptr;  // measurement: every class on the batch's stream
+    const bool fork = n_launch > 1 && b->side[0] != nullptr && !no_fork;
     int used = 0, slot = 0;
     auto next_stream = [&]() -> hipStream_t {
         if (!fork) return b->stream;
@@ -1255,7 +481,7 @@ void enqueue_zones(heat_batch *b, int mode) {
     int nl = b->n_touched;
     if (mode == 3) { zl = b->d_stream_zones.p; nl = b->n_stream_zones; }
     if (mode == 4) { zl = b->d_zlist_stream.p; nl = b->n_touched_stream; mode = 2; }  // sharded, beside a fused march
-    launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_T.p, b->d_side_out.p, b->d_zone_a0.p, b->d_zone_b0.p,
+    launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_zone_contrib.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
                  b->d_flags.p, mode, zl, nl, b->d_slot_of.p, b->n_shared, b->stream);
 }
@@ -1369,8 +595,12 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
     if (opt.n_ranks < 1) opt.n_ranks = 1;
     if (opt.nodes_per_lane != 0 && opt.nodes_per_lane != 4 && opt.nodes_per_lane != 8 && opt.nodes_per_lane != 16)
         return fail(HEAT_E_INVALID_ARG, "nodes_per_lane must be 0, 4, 8 or 16");
-    int rc = check_desc(desc);
-    if (rc) return rc;
+    int rc;
+    {
+        std::string err;
+        rc = check_desc(desc, err);
+        if (rc) return fail(rc, "%s", err.c_str());
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)

@@ -53,6 +53,17 @@ __device__ __forceinline__ double boundary_temperature(const SideConst &c, const
     return w.t_out;
 }
 
+// A Space-facing side's position in its zone's contribution list (stored in the `ambient` slot, layout.hpp).
+__device__ __forceinline__ long long side_entry_pos(const SideConst &c) { return __double_as_longlong(c.ambient); }
+__device__ __forceinline__ void put_zone_contrib(const SideArrays &sd, const SideConst &c, double hs, double t_face) {
+    if ((c.kind_n & 3) == KIND_SPACE) {
+        ZoneContrib z;
+        z.hs = hs;
+        z.t_face = t_face;
+        sd.zc[side_entry_pos(c)] = z;
+    }
+}
+
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
 
 // Neighbour exchange across the whole wavefront as DPP rotates (VALU speed; a ds_bpermute round trip through the
@@ -316,6 +327,13 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
     for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
     sd.out[d] = of;
     sd.out[S + d] = ob;
+    {
+        double Tl = T[0];
+#pragma unroll
+        for (int j = 1; j < kSmallNodes; j++) Tl = (j == nn - 1) ? T[j] : Tl;
+        put_zone_contrib(sd, cf, of.hs, T[0]);
+        put_zone_contrib(sd, cb, ob.hs, Tl);
+    }
     if (bad) atomicOr(flags, bad);
     nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
 }
@@ -455,7 +473,7 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
 // (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1; with cavities, M <= 8.)
 // SMALL = 1: the workgroup may also hold wavefronts of small all-no-mass surfaces (fused_small_wave).
 template <int M, int NM, int PAL, int CAV, int FUSED, int SMALL = 0>
-__global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, FUSED ? 2 : 1)
+__global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, (FUSED || (M == 16 && !CAV)) ? 2 : 1)
 k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                 const double *__restrict__ zone_T, int *__restrict__ flags,
@@ -690,7 +708,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // FRONT surface temperature (back/Ambient takes t_front and the front temperature, surface.rs:672-686).
     // Kept in plain scalars (a struct here ends up in scratch memory).
     auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, int lz, double &air_t,
-                       double &rad_t, double &forced, double &fix, bool &use_front_T) {
+                       double &rad_t, double &forced, bool &use_front_T) {
         const int kind = cc.kind_n & 3;
         air_t = btemp(cc, lz);
         rad_t = air_t;
@@ -707,12 +725,16 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             rad_t = btemp(fc, flz);
             use_front_T = true;
         }
-        fix = (sd.hs_fix != nullptr) ? sd.hs_fix[rec] : __builtin_nan("");  // surface.rs:708-714
     };
-    auto conv = [&](double air_t, double forced, double nat_pos, double nat_neg, double fix, double surf_t) {
+    // (the debug override of a side, surface.rs:708-714, is read where it is applied — a uniform branch on a
+    // pointer that is null in production — instead of living in two registers across the RK stages)
+    auto conv = [&](double air_t, double forced, double nat_pos, double nat_neg, int rec, double surf_t) {
         double hs = forced + tarp_natural_coef(air_t, surf_t, nat_pos, nat_neg, bad);  // convection.rs:165-167
         if (hs != hs) bad |= FLAG_NAN_HS;                                // surface.rs:704-707
-        if (fix == fix) hs = fix;
+        if (sd.hs_fix != nullptr) {
+            const double fix = sd.hs_fix[rec];
+            if (fix == fix) hs = fix;
+        }
         return hs;
     };
 
@@ -734,11 +756,11 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // add_face returns the face conductance and source through h_out / q_out (the caller files them
     // under front or back with selects: storing through a runtime side index lands in scratch).
     auto add_face = [&](const SideConst &cc, const SideDyn &dd, bool back, double air_t, double rad_t, double forced,
-                        double fix, bool use_front_T, double &h_out, double &q_out) {
+                        int rec, bool use_front_T, double &h_out, double &q_out) {
         h_out = 0.0;
         q_out = 0.0;
         const double surf_t = (back && !use_front_T) ? Tn : T0;
-        const double hs = conv(air_t, forced, cc.cos_eff, cc.alpha, fix, surf_t);  // (fast classes: the two coefficients)
+        const double hs = conv(air_t, forced, cc.cos_eff, cc.alpha, rec, surf_t);  // (fast classes: the two coefficients)
         const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
         const double sol = dd.solar;                        // absorbed: alpha * irradiance, formed at upload
         if constexpr (NM) {
@@ -795,26 +817,26 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         q_out = (air_t * hs + rhs * (rad_t - tface)) + sol;
     };
 
-    double my_air, my_rad, my_forced, my_fix;
+    double my_air, my_rad, my_forced;
     bool my_useF;
-    prepare(c, dy, my_back, sidx, my_lz, my_air, my_rad, my_forced, my_fix, my_useF);
+    prepare(c, dy, my_back, sidx, my_lz, my_air, my_rad, my_forced, my_useF);
     if (is_first || is_last) {
         double h_, q_;
-        add_face(c, dy, my_back, my_air, my_rad, my_forced, my_fix, my_useF, h_, q_);
+        add_face(c, dy, my_back, my_air, my_rad, my_forced, sidx, my_useF, h_, q_);
         hF = my_back ? 0.0 : h_;
         qF = my_back ? 0.0 : q_;
         hB = my_back ? h_ : 0.0;
         qB = my_back ? q_ : 0.0;
     }
-    double b_air = 0.0, b_forced = 0.0, b_fix = 0.0, b_cos = 0.0, b_neg = 0.0;
+    double b_air = 0.0, b_forced = 0.0, b_cos = 0.0, b_neg = 0.0;
     bool b_useF = false;
     if constexpr (!FUSED) {
         if (k == 1) {  // single-lane surfaces: this lane is also the last one
             double b_rad;
-            prepare(cb2, db2, true, S + d, 0, b_air, b_rad, b_forced, b_fix, b_useF);
+            prepare(cb2, db2, true, S + d, 0, b_air, b_rad, b_forced, b_useF);
             b_cos = cb2.cos_eff;
             b_neg = cb2.alpha;
-            add_face(cb2, db2, true, b_air, b_rad, b_forced, b_fix, b_useF, hB, qB);
+            add_face(cb2, db2, true, b_air, b_rad, b_forced, S + d, b_useF, hB, qB);
         }
     }
 
@@ -870,19 +892,33 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     const double Tnn = Tln;
     {
         const double surf_t = (my_back && !my_useF) ? Tnn : T0n;
-        const double hs = conv(my_air, my_forced, c.cos_eff, c.alpha, my_fix, surf_t);
+        const double hs = conv(my_air, my_forced, c.cos_eff, c.alpha, sidx, surf_t);
         const double face_t = my_back ? Tln : T[0];
         o_hs = hs;
         o_flow = (face_t - my_air) * hs;
+        if constexpr (!FUSED) {
+            // this side's share of its zone's heat balance, stored while the side record is still at hand
+            // (its position in the zone's list is fetched again, an L2 hit: held across the RK stages its two
+            // registers push the 16-node variant over the 256 of two wavefronts per SIMD)
+            if (active && (is_first || is_last) && (kind_n_mine & 3) == KIND_SPACE) {
+                int s2 = sidx;
+                asm volatile("" : "+v"(s2));
+                ZoneContrib z;
+                z.hs = hs;
+                z.t_face = face_t;
+                sd.zc[__double_as_longlong(sd.sc[s2].ambient)] = z;
+            }
+        }
         if constexpr (FUSED) {
             if (active && (is_first || is_last) && (c.kind_n & 3) == KIND_SPACE)
                 s_hT[(my_back ? kLanes : 0) + wib * kWave + lane] = make_double2(hs * my_area, face_t);
         }
     }
     if (!FUSED && k == 1) {
-        const double hs = conv(b_air, b_forced, b_cos, b_neg, b_fix, b_useF ? T0n : Tnn);
+        const double hs = conv(b_air, b_forced, b_cos, b_neg, S + d, b_useF ? T0n : Tnn);
         o2_hs = hs;
         o2_flow = (Tln - b_air) * hs;
+        if (active) put_zone_contrib(sd, cb2, hs, Tln);
     } else if (!(is_first || is_last)) {
         bad = 0;
     }
@@ -1140,6 +1176,8 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
         ob.hs = bh; ob.flow = (Tnn - t_back_b) * bh;
         sd.out[d] = of;
         sd.out[S + d] = ob;
+        put_zone_contrib(sd, cf, fh, T0n);
+        put_zone_contrib(sd, cb, bh, Tnn);
     }
     if (bad) atomicOr(flags, bad);
     if (iters) nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
@@ -1159,7 +1197,7 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
 //           compact partial[2][n_shared] at its slot for the exchange.
 __global__ void __launch_bounds__(256)
 k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entries,
-        const double *__restrict__ T, const SideOut *__restrict__ out,
+        const ZoneContrib *__restrict__ zc,
         const double *__restrict__ a0, const double *__restrict__ b0, const double *__restrict__ zone_vol,
         double *__restrict__ zone_T, double *__restrict__ partial, int n_zones, double dt,
         int *__restrict__ step_ptr, int *__restrict__ flags, int mode, const int32_t *__restrict__ zlist,
@@ -1177,19 +1215,18 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
     const int64_t e0 = zone_off[z], e1 = zone_off[z + 1];
     // the zone's own terms are fetched beside the first entries (their latency is then off the serial tail)
     const double za0 = a0[z], zb0 = b0[z], tc = zone_T[z], zv = zone_vol[z];
-    // two entries per lane and pass: both chains of dependent gathers (entry -> hs, T) are in flight together
+    // the surface kernels have left every side's (hs, face temperature) at its place in the zone's list: two
+    // contiguous streams, two entries per lane and pass
     for (int64_t e = e0 + lane; e < e1; e += 2 * kWave) {  // model.rs:562-585
         const bool two = e + kWave < e1;
-        const ZoneEntry en0 = entries[e];
-        const ZoneEntry en1 = entries[two ? e + kWave : e];
-        const double h0 = out[en0.hs_index].hs, h1 = out[en1.hs_index].hs;
-        const double t0 = T[en0.t_index], t1 = T[en1.t_index];
-        const double ha0 = h0 * en0.area;
-        a += ha0 * t0;
+        const int64_t e2 = two ? e + kWave : e;
+        const ZoneContrib c0 = zc[e], c1 = zc[e2];
+        const double ha0 = c0.hs * entries[e].area;
+        a += ha0 * c0.t_face;
         b += ha0;
         if (two) {
-            const double ha1 = h1 * en1.area;
-            a += ha1 * t1;
+            const double ha1 = c1.hs * entries[e2].area;
+            a += ha1 * c1.t_face;
             b += ha1;
         }
     }
@@ -1498,14 +1535,14 @@ void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_ti
                            gen_base, sa, cavs, weather, step_ptr, step_fixed, zone_T, flags, nomass_iters);
 }
 
-void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
+void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const ZoneContrib *zc,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
                   const int32_t *slot_of, int n_shared, hipStream_t st) {
     const int n_waves = (mode == 2 || mode == 3) ? n_list : n_zones;
     if (mode == 2 && n_waves <= 0) return;
     const int nb = n_waves > 0 ? blocks_for_waves(n_waves) : 1;
-    hipLaunchKernelGGL(k_zones, dim3(nb), dim3(256), 0, st, zone_off, entries, T, hs, a0, b0, zone_vol, zone_T,
+    hipLaunchKernelGGL(k_zones, dim3(nb), dim3(256), 0, st, zone_off, entries, zc, a0, b0, zone_vol, zone_T,
                        partial, n_zones, dt, step_ptr, flags, mode, zlist, n_list, slot_of, n_shared);
 }
 

@@ -26,7 +26,7 @@ void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_ti
                            int64_t gen_base, const SideArrays &sa, const CavityDev *cavs,
                            const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
                            int *flags, unsigned long long *nomass_iters, hipStream_t st);
-void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const double *T, const SideOut *hs,
+void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const ZoneContrib *zc,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
                   const int32_t *slot_of, int n_shared, hipStream_t st);

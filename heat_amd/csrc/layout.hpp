@@ -54,7 +54,9 @@ struct alignas(16) SideConst {
     int32_t kind_n;   // bits 0-1: boundary kind; bit 2: always windward (|cos tilt| >= 0.98,
                       // reference src/surface.rs:38); bits 16-31: node count of the surface
     int32_t zone;     // zone index when kind == KIND_SPACE
-    double ambient;   // Boundary::AmbientTemperature { temperature }
+    double ambient;   // kind == KIND_AMBIENT: Boundary::AmbientTemperature { temperature };
+                      // kind == KIND_SPACE: the bits of an int64 — this side's position in the zone contribution
+                      // list (ZoneEntry / SideArrays::zc), see side_entry_pos()
     double emis;      // thermal emissivity of this face (src/surface.rs:335,338)
     double alpha;     // general / small classes: solar absorptance of the face node (front_alphas[0] / back_alphas[n-1]).
                       // FAST classes: TARP natural-convection coefficient for air COLDER than the surface, h / |dT|^(1/3)
@@ -77,11 +79,20 @@ struct alignas(16) SideOut {
     double flow;      // convective heat flow
 };
 
+// A zone-facing side's share of calculate_zones_abc (model.rs:562-585): the new convection coefficient and the new
+// face temperature; k_zones multiplies by the area of the entry.
+struct alignas(16) ZoneContrib {
+    double hs;
+    double t_face;
+};
+
 struct SideArrays {
     const SideConst *sc;   // [2 * S]
     const SideDyn *dyn;    // [2 * S]
     SideOut *out;          // [2 * S]
     const double *hs_fix;  // [2 * S] debug overrides (src/surface.rs:374-380), NaN = none; nullable
+    ZoneContrib *zc;       // [zone entries]: what each zone-facing side adds to its zone's heat balance, written by the
+                           // surface kernels at the side's position in the zone's list (model.rs:562-585)
     int32_t S;
     int32_t pad;
 };
@@ -166,5 +177,7 @@ struct ZoneEntry {
     uint32_t hs_index;  // side record index (side * S + d) into SideArrays::out
     double area;
 };
+// (k_zones reads `area` only: the coefficient and the face temperature of entry e come from SideArrays::zc[e],
+// which the surface kernels fill — contiguous per zone instead of two gathers per entry.)
 
 }  // namespace heat
