@@ -113,6 +113,9 @@ SYMBOLS = [
     ("heat_batch_class_counts", C.c_int, [_H, _i64p]),
     ("heat_batch_set_timing", C.c_int, [_H, C.c_int32]),
     ("heat_batch_get_timing", C.c_int, [_H, _dp, _dp, _i64p]),
+    ("heat_partition", C.c_int, [C.POINTER(Desc), C.c_int32, _i32p, _i64p]),
+    ("heat_batch_create_shard", C.c_int, [C.POINTER(Desc), C.POINTER(Options), _i32p, C.POINTER(_H)]),
+    ("heat_plan_check", C.c_int, [C.POINTER(Desc), C.POINTER(Options), _i64p]),
     ("heat_last_error", C.c_char_p, []),
     ("heat_amd_abi_version", C.c_int, []),
     # include/heat_amd_setup.h
@@ -223,6 +226,61 @@ def make_desc(md):
     return d, keep
 
 
+HOST_ONLY_SYMBOLS = ("heat_partition", "heat_plan_check", "heat_last_error", "heat_amd_abi_version")
+
+
+def load_host_library(path):
+    """Binds the host-only entry points (csrc/plan.cpp) of a library built without HIP: the sanitizer build of the
+    planner that tests/test_planner_host.py runs in a child process."""
+    L = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        if name in HOST_ONLY_SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+    return L
+
+
+def make_options(device=-1, force_general=False, nodes_per_lane=0, use_graph=False, stream=None, n_ranks=1, rank=0,
+                 no_palette=False, no_fusion=False, fuse_always=False):
+    opt = Options()
+    opt.device = device
+    opt.force_general = 1 if force_general else 0
+    opt.nodes_per_lane = nodes_per_lane
+    opt.use_graph = 1 if use_graph else 0
+    opt.stream = stream
+    opt.n_ranks = n_ranks
+    opt.rank = rank
+    opt.no_palette = 1 if no_palette else 0
+    opt.no_fusion = 1 if no_fusion else (2 if fuse_always else 0)
+    return opt
+
+
+def partition(md, n_ranks, lib=None):
+    """heat_partition: (rank of every surface, number of zones shared between ranks). Host-only."""
+    L = lib or load_library()
+    desc, keep = make_desc(md)
+    ranks = np.zeros(int(md["n_surfaces"]), dtype=np.int32)
+    n_shared = C.c_int64(0)
+    rc = L.heat_partition(C.byref(desc), n_ranks, ranks.ctypes.data_as(_i32p), C.byref(n_shared))
+    if rc != 0:
+        raise HeatError(rc, L.heat_last_error().decode("utf-8", "replace"))
+    return ranks, int(n_shared.value)
+
+
+def plan_check(md, lib=None, **opts):
+    """heat_plan_check: plans the model as heat_batch_create_ex would and verifies the plan. Returns the summary
+    (surfaces per class [5], fused surfaces, fused workgroups, tiles). Host-only."""
+    L = lib or load_library()
+    desc, keep = make_desc(md)
+    opt = make_options(**opts)
+    summary = (C.c_int64 * 8)()
+    rc = L.heat_plan_check(C.byref(desc), C.byref(opt), summary)
+    if rc != 0:
+        raise HeatError(rc, L.heat_last_error().decode("utf-8", "replace"))
+    return list(summary)
+
+
 def comm_unique_id():
     """ncclGetUniqueId through the library (128 bytes). One rank calls it and hands the bytes to the others."""
     buf = (C.c_uint8 * 128)()
@@ -234,21 +292,21 @@ class HeatBatch:
     """Device-resident batch of surfaces + zones (≙ ThermalModel, src/model.rs:54-77)."""
 
     def __init__(self, md, device=-1, force_general=False, nodes_per_lane=0, use_graph=False, stream=None,
-                 n_ranks=1, rank=0, no_palette=False, no_fusion=False, fuse_always=False):
+                 n_ranks=1, rank=0, no_palette=False, no_fusion=False, fuse_always=False, rank_of_surface=None):
+        """rank_of_surface (heat_partition's result): the batch holds the surfaces of `rank` only, picked from the
+        whole model's dict by the library (heat_batch_create_shard)."""
         self._L = load_library()
         self._h = _H()
         desc, keep = make_desc(md)
-        opt = Options()
-        opt.device = device
-        opt.force_general = 1 if force_general else 0
-        opt.nodes_per_lane = nodes_per_lane
-        opt.use_graph = 1 if use_graph else 0
-        opt.stream = stream
-        opt.n_ranks = n_ranks
-        opt.rank = rank
-        opt.no_palette = 1 if no_palette else 0
-        opt.no_fusion = 1 if no_fusion else (2 if fuse_always else 0)
-        _check(self._L.heat_batch_create_ex(C.byref(desc), C.byref(opt), C.byref(self._h)))
+        opt = make_options(device, force_general, nodes_per_lane, use_graph, stream, n_ranks, rank, no_palette,
+                           no_fusion, fuse_always)
+        if rank_of_surface is None:
+            _check(self._L.heat_batch_create_ex(C.byref(desc), C.byref(opt), C.byref(self._h)))
+        else:
+            ros = np.ascontiguousarray(rank_of_surface, dtype=np.int32)
+            assert len(ros) == int(md["n_surfaces"])
+            _check(self._L.heat_batch_create_shard(C.byref(desc), C.byref(opt), ros.ctypes.data_as(_i32p),
+                                                   C.byref(self._h)))
         self.n_state = int(md["n_state"])
         self.n_zones = int(md["n_zones"])
         self.n_surfaces = int(md["n_surfaces"])

@@ -56,6 +56,24 @@ def build_example(force=False):
     return EXAMPLE_BIN
 
 
+PLAN_HOST_LIB = os.path.join(LIB_DIR, "libheat_plan_host.so")
+
+
+def build_plan_host(force=False):
+    """The planner on its own (csrc/plan.cpp, host-only), compiled by g++ with AddressSanitizer + UBSan: the library
+    tests/test_planner_host.py loads in a child process (LD_PRELOAD of libasan). Not part of the product."""
+    src = os.path.join(CSRC, "plan.cpp")
+    deps = [src, os.path.join(CSRC, "plan.hpp"), os.path.join(CSRC, "layout.hpp"),
+            os.path.join(HERE, "..", "include", "heat_amd.h")]
+    if not force and os.path.exists(PLAN_HOST_LIB) and os.path.getmtime(PLAN_HOST_LIB) >= max(map(os.path.getmtime, deps)):
+        return PLAN_HOST_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", src,
+                           "-o", PLAN_HOST_LIB])
+    return PLAN_HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_example(force="--force" in sys.argv))

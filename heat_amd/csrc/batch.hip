@@ -28,15 +28,13 @@ using namespace heat;
 
 namespace {
 
-thread_local std::string g_last_error;
-
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_last_error = buf;
+    heat::last_error() = buf;
     return code;
 }
 
@@ -173,12 +171,22 @@ struct heat_batch {
     bool staged = false;
     int n_fast_tiles[kNumFast] = {};
     DevBuf<FastTile> d_fast_tiles[kNumFast];
+    std::vector<FastTile> h_tiles_cur[kNumFast];  // the tile lists as they are on the device now
+    // Unified streamed lists (k_surfaces_stream): the palette-form fast classes and the cavity-free small surfaces in
+    // one tile list. [0]: the streamed tiles only (beside a cluster-resident march), [1]: every tile.
+    DevBuf<FastTile> d_ulist[2];
+    int n_ulist[2] = {0, 0};
+    bool in_ulist[2][kNumFast] = {};
+    bool small_in_ulist[2] = {false, false};
+    DevBuf<unsigned long long> d_ucount;  // no-mass pass counters of the unified lists: [list][tile]
+    size_t ucount_stride = 0;
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
     int n_small_tiles = 0;      // small tiles, cavity-free ones first
     int n_small_plain_tiles = 0;
     int n_smallcav_stream_tiles = 0;  // streamed small-with-cavity tiles; the fused workgroups' small tiles follow them
     int n_smallcav_stream_tiles0 = 0;
     std::vector<GeneralTile> h_gen_tiles0;
+    std::vector<GeneralTile> h_gen_tiles_cur;  // as on the device now
     size_t nm_count_base[kNumFast + 1] = {};
     DevBuf<GeneralTile> d_gen_tiles;
     int64_t gen_base = 0;     // first node slot of the general group
@@ -277,6 +285,8 @@ int flags_to_status(int f) {
     return HEAT_OK;
 }
 
+int rebuild_unified(heat_batch *b);
+
 int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt) {
     // Classification, clustering, tiling and packing are host-only work (plan.cpp); here the plan is uploaded.
     Plan p;
@@ -309,13 +319,13 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         b->n_stream_zones = (int)sz.size();
         HIP_TRY(b->d_stream_zones.upload(sz));
     }
-    b->h_gen_tiles0 = p.gen_tiles;
+    b->h_gen_tiles0 = b->h_gen_tiles_cur = p.gen_tiles;
     for (int c = 0; c < kNumFast; c++) {
         for (int g2 = 0; g2 < 4; g2++) {
             b->h_fblocks[c][g2] = b->h_fblocks0[c][g2] = p.fblocks[c][g2];
             HIP_TRY(b->d_fblocks[c][g2].upload(p.fblocks[c][g2]));
         }
-        b->h_tiles0[c] = p.fast_tiles[c];
+        b->h_tiles0[c] = b->h_tiles_cur[c] = p.fast_tiles[c];
         b->n_stream_tiles[c] = b->n_stream_tiles0[c] = p.n_stream_tiles[c];
         b->n_fast_tiles[c] = (int)p.fast_tiles[c].size();
         HIP_TRY(b->d_fast_tiles[c].upload(p.fast_tiles[c]));
@@ -376,6 +386,11 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_nomass_iters.zeros(p.n_nm_counters));
     if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
 
+    {
+        const int rc = rebuild_unified(b);
+        if (rc) return rc;
+    }
+
     // ---- argument bundles ----
     SideArrays &sa = b->sa;
     sa.sc = b->d_side_const.p;
@@ -402,11 +417,79 @@ int select_device(heat_batch *b) {
     return HEAT_OK;
 }
 
+// The unified streamed tile lists from the current per-class lists (create time, and again when
+// heat_batch_set_shared_zones has moved tiles between the fused workgroups and the streamed part).
+int rebuild_unified(heat_batch *b) {
+    static const bool off = getenv("HEAT_AMD_NO_UNIFIED") != nullptr;  // measurement: one launch per class as before
+    auto eligible = [](int c) { return kFastPAL[c] && !kFastCAV[c] && !(kFastM[c] == 16 && kFastNM[c]); };
+    size_t cap = (size_t)b->n_small_plain_tiles;
+    for (int c = 0; c < kNumFast; c++) if (eligible(c)) cap += b->h_tiles_cur[c].size();
+    if (b->d_ucount.n == 0) {
+        b->ucount_stride = std::max<size_t>(cap, 1);
+        HIP_TRY(b->d_ucount.zeros(2 * b->ucount_stride));
+    }
+    const int ns = b->n_small_plain_tiles;
+    for (int v = 0; v < 2; v++) {
+        std::vector<FastTile> fast;
+        int n_classes = 0;
+        for (int mi = 2; mi >= 0; mi--)  // 16 nodes per lane first: the heaviest tiles lead
+            for (int c = mi * 6; c < mi * 6 + 6; c++) {
+                if (!eligible(c)) continue;
+                const int n = v ? b->n_fast_tiles[c] : b->n_stream_tiles[c];
+                n_classes += n > 0;
+                for (int t = 0; t < n; t++) {
+                    FastTile ft = b->h_tiles_cur[c][t];
+                    ft.k = (int16_t)((ft.k & 0x1ff) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
+                    fast.push_back(ft);
+                }
+            }
+        // worth it when it replaces two launches or more (a class on its own keeps its own persistent kernel)
+        const bool use = !off && (n_classes + (ns > 0)) >= 2;
+        b->n_ulist[v] = 0;
+        for (int c = 0; c < kNumFast; c++) b->in_ulist[v][c] = use && eligible(c);
+        b->small_in_ulist[v] = use && ns > 0;
+        if (!use) continue;
+        // the latency-bound small tiles are spread evenly through the list
+        const size_t N = fast.size() + (size_t)ns;
+        std::vector<FastTile> list(N);
+        std::vector<uint8_t> taken(N, 0);
+        for (int j = 0; j < ns; j++) {
+            size_t pos = (size_t)(((double)j + 0.5) * (double)N / (double)ns);
+            if (pos >= N) pos = N - 1;
+            while (taken[pos]) pos = (pos + 1) % N;
+            const GeneralTile &g = b->h_gen_tiles_cur[j];
+            FastTile ft;
+            ft.node_base = g.node_base;
+            ft.surf_base = g.surf_base;
+            ft.k = (int16_t)(kStreamKindSmall << kStreamKindShift);
+            ft.G = (int16_t)g.G;
+            list[pos] = ft;
+            taken[pos] = 1;
+        }
+        size_t q = 0;
+        for (size_t pos = 0; pos < N; pos++)
+            if (!taken[pos]) list[pos] = fast[q++];
+        if (N > b->ucount_stride) return fail(HEAT_E_SIZE, "unified tile list grew beyond its counters");
+        b->n_ulist[v] = (int)N;
+        HIP_TRY(b->d_ulist[v].upload(list));
+    }
+    return HEAT_OK;
+}
+
 // iterate_surfaces for every group (model.rs:388-408), one sub-timestep.
 // streamed_only: leave out the tiles owned by the cluster-resident march (enqueue_fused marches those).
 void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false) {
     int nt[kNumFast];
     for (int c = 0; c < kNumFast; c++) nt[c] = streamed_only ? b->n_stream_tiles[c] : b->n_fast_tiles[c];
+    // One launch for the palette-form fast classes and the cavity-free small surfaces (k_surfaces_stream); the
+    // classes it does not hold follow on their own.
+    const int ul = streamed_only ? 0 : 1;
+    const bool unified = b->n_ulist[ul] > 0;
+    int n_small_plain = b->n_small_plain_tiles;
+    if (unified) {
+        for (int c = 0; c < kNumFast; c++) if (b->in_ulist[ul][c]) nt[c] = 0;
+        if (b->small_in_ulist[ul]) n_small_plain = 0;
+    }
     // The classes are independent (model.rs:102-180: surfaces never read what another surface wrote in the
     // same sub-timestep): spread them over the batch's stream and its side streams so that one class's
     // tail overlaps the next class's head.
@@ -414,7 +497,8 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     for (int c = 0; c < kNumFast; c++) n_launch += nt[c] > 0;
     // small tiles with cavities: the streamed ones come first, the fused workgroups' after them
     const int n_cav_tiles = streamed_only ? b->n_smallcav_stream_tiles : b->n_small_tiles - b->n_small_plain_tiles;
-    n_launch += b->n_small_plain_tiles > 0;
+    n_launch += unified;
+    n_launch += n_small_plain > 0;
     n_launch += n_cav_tiles > 0;
     n_launch += b->n_gen_tiles > b->n_small_tiles;
     static const bool no_fork = getenv("HEAT_AMD_NO_FORK") != nullptr;  // measurement: every class on the batch's stream
@@ -431,6 +515,9 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         (void)hipEventRecord(b->ev_fork, b->stream);
         for (int i = 0; i < heat_batch::kSideStreams; i++) (void)hipStreamWaitEvent(b->side[i], b->ev_fork, 0);
     }
+    if (unified)
+        launch_surfaces_stream(b->d_ulist[ul].p, b->n_ulist[ul], b->na, b->gen_base, b->sa, b->d_weather.p, b->d_step.p,
+                               step_fixed, b->d_zone_T.p, b->d_flags.p, b->d_ucount.p + ul * b->ucount_stride, next_stream());
     // work of each class in node slots, to size the persistent grids
     double work[kNumFast], total_work = 0.0;
     for (int c = 0; c < kNumFast; c++) {
@@ -451,8 +538,8 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
                              b->d_nomass_iters.p + b->nm_count_base[c], next_stream());
     }
     unsigned long long *cnt = b->d_nomass_iters.p + b->nm_count_base[kNumFast];
-    if (b->n_small_plain_tiles > 0)
-        launch_surfaces_small(0, b->d_gen_tiles.p, b->n_small_plain_tiles, b->na, b->gen_base, b->sa, b->d_cavs.p,
+    if (n_small_plain > 0)
+        launch_surfaces_small(0, b->d_gen_tiles.p, n_small_plain, b->na, b->gen_base, b->sa, b->d_cavs.p,
                               b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p, cnt,
                               next_stream());
     if (n_cav_tiles > 0)
@@ -573,8 +660,6 @@ hipEvent_t next_event(heat_batch *b) {
 // ===========================================================================
 extern "C" {
 
-const char *heat_last_error(void) { return g_last_error.c_str(); }
-int heat_amd_abi_version(void) { return HEAT_AMD_ABI_VERSION; }
 
 int heat_batch_create(const heat_batch_desc *desc, heat_batch **out) {
     heat_batch_options opt;
@@ -645,6 +730,22 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
     }
     *out = b;
     return HEAT_OK;
+}
+
+int heat_batch_create_shard(const heat_batch_desc *desc, const heat_batch_options *opt, const int32_t *rank_of_surface,
+                            heat_batch **out) {
+    if (!desc || !opt || !rank_of_surface || !out) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    {
+        std::string err;
+        const int rc = check_desc(desc, err);
+        if (rc) return fail(rc, "%s", err.c_str());
+    }
+    for (int64_t s = 0; s < desc->n_surfaces; s++)
+        if (rank_of_surface[s] < 0 || rank_of_surface[s] >= std::max(opt->n_ranks, 1))
+            return fail(HEAT_E_SIZE, "surface %lld: rank %d outside [0, %d)", (long long)s, rank_of_surface[s], std::max(opt->n_ranks, 1));
+    ShardDesc sh;
+    sh.build(desc, rank_of_surface, opt->rank);
+    return heat_batch_create_ex(&sh.desc, opt, out);
 }
 
 void heat_batch_destroy(heat_batch *b) {
@@ -857,6 +958,7 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         g.insert(g.end(), g0.begin() + b->n_small_tiles, g0.end());
         b->n_smallcav_stream_tiles = b->n_smallcav_stream_tiles0 + n_demoted;
         HIP_TRY(b->d_gen_tiles.upload(g));
+        b->h_gen_tiles_cur = g;
     }
     for (int c = 0; c < kNumFast; c++) {
         const std::vector<FastTile> &t0 = b->h_tiles0[c];
@@ -891,6 +993,7 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         }
         b->n_stream_tiles[c] = (int)t.size() - n_kept_tiles;
         HIP_TRY(b->d_fast_tiles[c].upload(t));
+        b->h_tiles_cur[c] = t;
     }
     {
         std::vector<int32_t> szl, tz;
@@ -905,6 +1008,8 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         HIP_TRY(b->d_zlist_stream.upload(tz));
     }
     b->n_fused_surfaces = n_fused_now;
+    rc = rebuild_unified(b);
+    if (rc) return rc;
     if (b->graph_exec) {  // the captured sub-timestep graph holds the old tile counts
         (void)hipGraphExecDestroy(b->graph_exec);
         b->graph_exec = nullptr;
@@ -1136,6 +1241,12 @@ int64_t heat_batch_nomass_iterations(heat_batch *b) {
         return -1;
     unsigned long long v = 0;
     for (unsigned long long x : h) v += x;
+    if (b->d_ucount.n) {
+        h.resize(b->d_ucount.n);
+        if (hipMemcpy(h.data(), b->d_ucount.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        for (unsigned long long x : h) v += x;
+    }
     return (int64_t)v;
 }
 

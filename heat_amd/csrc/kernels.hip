@@ -292,27 +292,25 @@ __device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, co
     }
 }
 
+// One tile of small surfaces (general layout: one lane per surface), one sub-timestep. Returns the lane's passes of
+// the no-mass loop.
 template <int CAV>
-__global__ void __launch_bounds__(256)
-k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
-                 SideArrays sd, const CavityDev *__restrict__ cavs,
-                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
-                 const double *__restrict__ zone_T, int *__restrict__ flags,
-                 unsigned long long *__restrict__ nomass_iters) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= n_tiles) return;
-    const GeneralTile tile = tiles[wave];
-    if (lane >= tile.G) return;
-    const int d = tile.surf_base + lane;
+__device__ __forceinline__ unsigned int small_tile_march(int64_t node_base, int surf_base, int G, int lane,
+                                                         const NodeArrays &na, int64_t gen_base, const SideArrays &sd,
+                                                         const StepWeather &w, const double *__restrict__ zone_T,
+                                                         int *__restrict__ flags) {
+    if (lane >= G) return 0;
+    GeneralTile tile;
+    tile.node_base = node_base;
+    tile.surf_base = surf_base;
+    tile.G = G;
+    const int d = surf_base + lane;
     const int S = sd.S;
     const SideConst cf = sd.sc[d];
     const SideConst cb = sd.sc[S + d];
     const SideDyn df = sd.dyn[d];
     const SideDyn db = sd.dyn[S + d];
     const int nn = cf.kind_n >> 16;
-    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
-    const StepWeather w = weather[step];
     double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
     int cav[kSmallNodes];
     CavityDev cv[kSmallNodes - 1];
@@ -322,7 +320,7 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
     SideOut of, ob;
     small_step<CAV>(cf, cb, df, db, sd.hs_fix, d, S, w, boundary_temperature(cf, w, zone_T),
                     boundary_temperature(cb, w, zone_T), nn, T, Us, sol, cav, cv, bad, iters, of, ob);
-    double *Tg = na.T + tile.node_base + lane;
+    double *Tg = na.T + node_base + lane;
 #pragma unroll
     for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
     sd.out[d] = of;
@@ -335,7 +333,24 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
         put_zone_contrib(sd, cb, ob.hs, Tl);
     }
     if (bad) atomicOr(flags, bad);
-    nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
+    return iters;
+}
+
+template <int CAV>
+__global__ void __launch_bounds__(256)
+k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
+                 SideArrays sd, const CavityDev *__restrict__ cavs,
+                 const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                 const double *__restrict__ zone_T, int *__restrict__ flags,
+                 unsigned long long *__restrict__ nomass_iters) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_tiles) return;
+    const GeneralTile tile = tiles[wave];
+    const int step = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const StepWeather w = weather[step];
+    const unsigned int iters = small_tile_march<CAV>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, w, zone_T, flags);
+    if (lane < tile.G) nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
 }
 #pragma clang fp contract(fast)
 
@@ -457,91 +472,23 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
 }
 #pragma clang fp contract(fast)
 
-// NM = 1: the surface may carry a no-mass FACING node (node 0 and/or node n-1, every other node
-// massive): each is a one-node no-mass chunk, solved by the reference's damped fixed-point loop
-// (march_nomass, surface.rs:790-898) in the face lane before the massive nodes march.
-// PAL = 1: V and U come from the surface's palette (staged in LDS) through one class byte per node
-// instead of two doubles per node (layout.hpp).
-// CAV = 1: up to two gas cavities between massive nodes; their conductance (Cavity::u_value, cavity.rs:59-69)
-// is evaluated once per sub-timestep from the temperatures the massive chunk starts from, as get_k_q does
-// (discretization.rs:634-639), and frozen over the four RK stages (surface.rs:268-293).
-// FUSED = 1: cluster-resident march (layout.hpp, FusedBlock). One workgroup holds every surface facing its
-// zones; it marches fa.n_sub sub-timesteps of ThermalModel::march (model.rs:369-424) in one launch: the node
-// temperatures never leave the registers, the zone balance (calculate_zones_abc + the analytic update,
-// model.rs:489-597,650-674) is summed from LDS in the same order and with the same arithmetic as k_zones, and
-// only the final temperatures, coefficients and flows are written back.
-// (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1; with cavities, M <= 8.)
-// SMALL = 1: the workgroup may also hold wavefronts of small all-no-mass surfaces (fused_small_wave).
-template <int M, int NM, int PAL, int CAV, int FUSED, int SMALL = 0>
-__global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, (FUSED || (M == 16 && !CAV)) ? 2 : 1)
-k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
-                const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
-                const double *__restrict__ zone_T, int *__restrict__ flags,
-                unsigned long long *__restrict__ nomass_iters, FusedArgs fa) {
-    static_assert(!FUSED || (PAL && !(CAV && M == 16)),
-                  "the cluster-resident march exists for palette classes; with gas cavities for 4 or 8 nodes per lane");
-    constexpr int kMaxW = FUSED ? FUSED : 4;
-    constexpr int kLanes = kMaxW * kWave;
-    // LDS: the palettes of the block's tiles; FUSED adds the per-side (hs, face temperature) pairs the zone
-    // balance is summed from, [2][kLanes] double2, and the zone temperatures (dynamic: > 64 KB for 8 waves).
-    extern __shared__ double s_dyn[];
-    __shared__ double s_pal_static[(PAL && !FUSED) ? kLanes * kPal : 2];
-    double *const s_pal = FUSED ? s_dyn : s_pal_static;
-    // FUSED, after the palettes: with 16 nodes per lane V = dt/C of every node, [M][kLanes] (read where it is used:
-    // held in registers over the march it would push that variant out of the register file); (hs * area, face temperature)
-    // per side [2][kLanes] double2; zone temperatures, a0, b0, volume [kFusedMaxZones] each; first slot of every
-    // zone [kFusedMaxZones + 1]; the slot lists.
+// One tile of a fast class: n_it sub-timesteps (one, unless FUSED) of its surfaces. The body of k_surfaces_fast and
+// of the fast-path cases of k_surfaces_stream.
+//   counter_index  slot of the tile in `nomass_iters` (NM)
+//   nm_on          NM variants: whether this tile holds walls with no-mass facings at all (wave-uniform; the unified
+//                  streamed kernel runs all-massive and faced tiles through one variant)
+template <int M, int NM, int PAL, int CAV, int FUSED>
+__device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter_index, bool nm_on, int lane, int wib,
+                                                double *s_pal, double *s_V, const FusedLds &fl, const FusedBlock &blk,
+                                                int blk_waves, int n_it, int step0, const NodeArrays &na,
+                                                const SideArrays &sd, const StepWeather *__restrict__ weather,
+                                                const double *__restrict__ zone_T, int *__restrict__ flags,
+                                                unsigned long long *__restrict__ nomass_iters, const FusedArgs &fa) {
+    constexpr int kLanes = (FUSED ? FUSED : 4) * kWave;
     constexpr bool kVinLds = FUSED && M == 16;
-    double *const s_V = s_dyn + kLanes * kPal;
-    FusedLds fl;
-    fl.hT = reinterpret_cast<double2 *>(s_V + (kVinLds ? M : 0) * kLanes);
-    fl.zT = reinterpret_cast<double *>(fl.hT) + 4 * kLanes;
-    fl.za0 = fl.zT + kFusedMaxZones;
-    fl.zb0 = fl.za0 + kFusedMaxZones;
-    fl.zvol = fl.zb0 + kFusedMaxZones;
-    fl.zoff = reinterpret_cast<int *>(fl.zvol + kFusedMaxZones);
-    fl.slots = reinterpret_cast<unsigned short *>(fl.zoff + kFusedMaxZones + 2);
     double2 *const s_hT = fl.hT;
     double *const s_zT = fl.zT;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = threadIdx.x >> 6;
-    int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
-    int n_waves = gridDim.x * (blockDim.x >> 6);
-    FusedBlock blk{0, 0, 0, 0, 0, 0};
-    int blk_waves = 0;  // wavefronts of the workgroup that have work
-    int bi = blockIdx.x;  // FUSED: the FusedBlock this workgroup marches
-    __shared__ int s_next_block;
-    const int n_it = FUSED ? fa.n_sub : 1;
-    const int step0 = FUSED ? 0 : ((step_fixed >= 0) ? step_fixed : *step_ptr);
-    // Streaming (FUSED = 0), persistent waves: each walks the tile list with a grid stride, so the write-back of
-    // one tile (a wave cannot retire before its stores are acknowledged) overlaps the loads of the next.
-    // FUSED: one pass per FusedBlock; with a work queue (sharded batches, fa.queue) the workgroup takes further ones.
-    for (int wave = wave0; FUSED ? (bi < fa.n_blocks) : (wave < n_tiles); wave += n_waves) {
-    if constexpr (FUSED) {
-        blk = fa.blocks[bi];
-        blk_waves = blk.n_tiles + (SMALL ? blk.n_small : 0);
-        if (wib >= blk_waves) {
-            // no tile for this wavefront. One FusedBlock per workgroup: done (a finished wave does not take part in
-            // s_barrier). With the queue it has to stay for the next block, and keeps step with the barriers.
-            if (fa.queue == nullptr) return;
-            __syncthreads();
-            for (int it = 0; it < fa.n_sub; it++) {
-                __syncthreads();
-                __syncthreads();
-            }
-            goto next_block;
-        }
-        if constexpr (SMALL) {
-            if (wib >= blk.n_tiles) {
-                fused_small_wave(blk, fa, fl, kLanes, wib, blk_waves, lane, na, sd, weather, flags);
-                if (fa.queue == nullptr) return;
-                goto next_block;
-            }
-        }
-        wave = blk.first_tile + wib;
-    }
-    {   // (a scope of its own: the jumps above pass over its declarations)
-    const FastTile tile = tiles[wave];
+    (void)s_hT; (void)s_zT; (void)s_V; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
     const int k = tile.k & 0xff;
     const bool full = (tile.k & 0x100) != 0;
     const int G = tile.G;
@@ -749,7 +696,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     if (is_first) UL = 0.0;
     // Last node of the previous lane (wave-wide exchange: must not sit inside a divergent branch).
     double T_prev_last = 0.0;
-    if constexpr (NM) T_prev_last = from_prev_lane(T[M - 1]);
+    if constexpr (NM) T_prev_last = from_prev_lane(T[M - 1]);  // (wave-wide: not under the nm_on gate of a lane)
 
     // Face terms of get_k_q (discretization.rs:658-697) + solar gains (surface.rs:916-931,766-769).
     double hF = 0.0, qF = 0.0, hB = 0.0, qB = 0.0;
@@ -768,7 +715,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             //   K = (0 - h_face) - u_inner,  q = (q_face + u_inner * T_inner) + solar,  x = -q / K,
             //   T <- (T + x) / 2 until the error stops shrinking or err < tol (surface.rs:836-895).
             const double vface = back ? V_last() : Vat(0);
-            if (active && vface == 0.0 && nn >= 2) {
+            if (nm_on && active && vface == 0.0 && nn >= 2) {
                 double u_in, t_in;
                 if (!back) {
                     u_in = U[0];
@@ -953,9 +900,93 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         unsigned int tot = nm_passes;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
-        if (lane == 0 && tot) nomass_iters[wave] += tot;
+        if (lane == 0 && tot) nomass_iters[counter_index] += tot;
     }
-    }  // (tile scope)
+}
+
+// NM = 1: the surface may carry a no-mass FACING node (node 0 and/or node n-1, every other node
+// massive): each is a one-node no-mass chunk, solved by the reference's damped fixed-point loop
+// (march_nomass, surface.rs:790-898) in the face lane before the massive nodes march.
+// PAL = 1: V and U come from the surface's palette (staged in LDS) through one class byte per node
+// instead of two doubles per node (layout.hpp).
+// CAV = 1: up to two gas cavities between massive nodes; their conductance (Cavity::u_value, cavity.rs:59-69)
+// is evaluated once per sub-timestep from the temperatures the massive chunk starts from, as get_k_q does
+// (discretization.rs:634-639), and frozen over the four RK stages (surface.rs:268-293).
+// FUSED = 1: cluster-resident march (layout.hpp, FusedBlock). One workgroup holds every surface facing its
+// zones; it marches fa.n_sub sub-timesteps of ThermalModel::march (model.rs:369-424) in one launch: the node
+// temperatures never leave the registers, the zone balance (calculate_zones_abc + the analytic update,
+// model.rs:489-597,650-674) is summed from LDS in the same order and with the same arithmetic as k_zones, and
+// only the final temperatures, coefficients and flows are written back.
+// (FUSED is the most wavefronts a workgroup may hold: 4 or 8; it needs PAL = 1; with cavities, M <= 8.)
+// SMALL = 1: the workgroup may also hold wavefronts of small all-no-mass surfaces (fused_small_wave).
+template <int M, int NM, int PAL, int CAV, int FUSED, int SMALL = 0>
+__global__ void __launch_bounds__(FUSED ? 64 * FUSED : 256, (FUSED || (M == 16 && !CAV)) ? 2 : 1)
+k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, SideArrays sd,
+                const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                const double *__restrict__ zone_T, int *__restrict__ flags,
+                unsigned long long *__restrict__ nomass_iters, FusedArgs fa) {
+    static_assert(!FUSED || (PAL && !(CAV && M == 16)),
+                  "the cluster-resident march exists for palette classes; with gas cavities for 4 or 8 nodes per lane");
+    constexpr int kMaxW = FUSED ? FUSED : 4;
+    constexpr int kLanes = kMaxW * kWave;
+    // LDS: the palettes of the block's tiles; FUSED adds the per-side (hs, face temperature) pairs the zone
+    // balance is summed from, [2][kLanes] double2, and the zone temperatures (dynamic: > 64 KB for 8 waves).
+    extern __shared__ double s_dyn[];
+    __shared__ double s_pal_static[(PAL && !FUSED) ? kLanes * kPal : 2];
+    double *const s_pal = FUSED ? s_dyn : s_pal_static;
+    // FUSED, after the palettes: with 16 nodes per lane V = dt/C of every node, [M][kLanes] (read where it is used:
+    // held in registers over the march it would push that variant out of the register file); (hs * area, face temperature)
+    // per side [2][kLanes] double2; zone temperatures, a0, b0, volume [kFusedMaxZones] each; first slot of every
+    // zone [kFusedMaxZones + 1]; the slot lists.
+    constexpr bool kVinLds = FUSED && M == 16;
+    double *const s_V = s_dyn + kLanes * kPal;
+    FusedLds fl;
+    fl.hT = reinterpret_cast<double2 *>(s_V + (kVinLds ? M : 0) * kLanes);
+    fl.zT = reinterpret_cast<double *>(fl.hT) + 4 * kLanes;
+    fl.za0 = fl.zT + kFusedMaxZones;
+    fl.zb0 = fl.za0 + kFusedMaxZones;
+    fl.zvol = fl.zb0 + kFusedMaxZones;
+    fl.zoff = reinterpret_cast<int *>(fl.zvol + kFusedMaxZones);
+    fl.slots = reinterpret_cast<unsigned short *>(fl.zoff + kFusedMaxZones + 2);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x >> 6;
+    int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
+    int n_waves = gridDim.x * (blockDim.x >> 6);
+    FusedBlock blk{0, 0, 0, 0, 0, 0};
+    int blk_waves = 0;  // wavefronts of the workgroup that have work
+    int bi = blockIdx.x;  // FUSED: the FusedBlock this workgroup marches
+    __shared__ int s_next_block;
+    const int n_it = FUSED ? fa.n_sub : 1;
+    const int step0 = FUSED ? 0 : ((step_fixed >= 0) ? step_fixed : *step_ptr);
+    // Streaming (FUSED = 0), persistent waves: each walks the tile list with a grid stride, so the write-back of
+    // one tile (a wave cannot retire before its stores are acknowledged) overlaps the loads of the next.
+    // FUSED: one pass per FusedBlock; with a work queue (sharded batches, fa.queue) the workgroup takes further ones.
+    for (int wave = wave0; FUSED ? (bi < fa.n_blocks) : (wave < n_tiles); wave += n_waves) {
+    if constexpr (FUSED) {
+        blk = fa.blocks[bi];
+        blk_waves = blk.n_tiles + (SMALL ? blk.n_small : 0);
+        if (wib >= blk_waves) {
+            // no tile for this wavefront. One FusedBlock per workgroup: done (a finished wave does not take part in
+            // s_barrier). With the queue it has to stay for the next block, and keeps step with the barriers.
+            if (fa.queue == nullptr) return;
+            __syncthreads();
+            for (int it = 0; it < fa.n_sub; it++) {
+                __syncthreads();
+                __syncthreads();
+            }
+            goto next_block;
+        }
+        if constexpr (SMALL) {
+            if (wib >= blk.n_tiles) {
+                fused_small_wave(blk, fa, fl, kLanes, wib, blk_waves, lane, na, sd, weather, flags);
+                if (fa.queue == nullptr) return;
+                goto next_block;
+            }
+        }
+        wave = blk.first_tile + wib;
+    }
+    fast_tile_march<M, NM, PAL, CAV, FUSED>(tiles[wave], wave, true, lane, wib, s_pal, s_V, fl, blk, blk_waves, n_it, step0, na,
+                                            sd, weather, zone_T, flags, nomass_iters, fa);
 next_block:
     if constexpr (FUSED) {
         if (fa.queue == nullptr) break;
@@ -965,6 +996,65 @@ next_block:
         bi = s_next_block;
     }
     }  // tile / block loop
+}
+
+// ---------------------------------------------------------------------------
+// The streamed sub-timestep in ONE launch (iterate_surfaces, model.rs:102-180, over every surface that is not
+// marched cluster-resident): persistent wavefronts walk a single tile list that holds the palette-form fast classes
+// of every blocking factor and the cavity-free small surfaces; FastTile::k carries the tile's kind —
+//   bits 9-10  0 / 1 / 2: fast-path tile of 4 / 8 / 16 nodes per lane; 3: small all-no-mass surfaces, one per lane
+//   bit 11     the tile holds walls with no-mass facings (8 and 4 nodes per lane only: the 16-node variant with
+//              facings does not fit two wavefronts per SIMD)
+// — a wave-uniform switch instead of one launch per class: no class has a tail of its own, the latency-bound
+// small tiles are spread through the list and disappear behind the streaming ones. Classes this kernel does not
+// hold (per-node constants, gas cavities, the catch-all) keep their own launches.
+constexpr int kTileKindShift = 9;
+constexpr int kTileNmBit = 1 << 11;
+__global__ void __launch_bounds__(256, 2)
+k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base, SideArrays sd,
+                  const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
+                  const double *__restrict__ zone_T, int *__restrict__ flags,
+                  unsigned long long *__restrict__ nomass_iters) {
+    __shared__ double s_pal[4 * kWave * kPal];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x >> 6;
+    const int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int step0 = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const FusedLds fl{};
+    const FusedBlock blk{0, 0, 0, 0, 0, 0};
+    const FusedArgs fa{};
+    if (wave0 >= n_tiles) return;
+    // (the tile descriptor is wave-uniform: scalar loads)
+    for (int wv = wave0; wv < n_tiles; wv += n_waves) {
+        const int w = __builtin_amdgcn_readfirstlane(wv);
+        FastTile tile = tiles[w];
+        const int kind = (tile.k >> kTileKindShift) & 3;
+        const bool nm = (tile.k & kTileNmBit) != 0;
+        tile.k = (int16_t)(tile.k & 0x1ff);
+        switch (kind) {
+        case 2:
+            fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather,
+                                            zone_T, flags, nomass_iters, fa);
+            break;
+        case 1:
+            fast_tile_march<8, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
+                                           flags, nomass_iters, fa);
+            break;
+        case 0:
+            fast_tile_march<4, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
+                                           flags, nomass_iters, fa);
+            break;
+        default: {
+            unsigned int tot = small_tile_march<0>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, weather[step0],
+                                                   zone_T, flags);
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
+            if (lane == 0 && tot) nomass_iters[w] += tot;
+            break;
+        }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1450,6 +1540,23 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     if (M == 4) { HEAT_LAUNCH_M(4) } else if (M == 8) { HEAT_LAUNCH_M(8) } else { HEAT_LAUNCH_M(16) }
 #undef HEAT_LAUNCH_M
 #undef HEAT_LAUNCH_FAST
+}
+
+// grid: persistent, two 4-wave blocks per compute unit (256 registers per lane), capped by the tile count.
+void launch_surfaces_stream(const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
+                            const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
+                            int *flags, unsigned long long *nomass_iters, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    static const int n_cu = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    static const int per_cu = getenv("HEAT_AMD_STREAM_BLOCKS") ? atoi(getenv("HEAT_AMD_STREAM_BLOCKS")) : 2;
+    const int grid = std::min(blocks_for_waves(n_tiles), n_cu * std::max(per_cu, 1));
+    hipLaunchKernelGGL(k_surfaces_stream, dim3(grid), dim3(256), 0, st, tiles, n_tiles, na, gen_base, sa, weather, step_ptr,
+                       step_fixed, zone_T, flags, nomass_iters);
 }
 
 // Cluster-resident march of one class: one workgroup of `max_waves` (4 or 8) wavefronts per FusedBlock, fa.n_sub

@@ -1200,4 +1200,51 @@ void ShardDesc::build(const heat_batch_desc *d, const int32_t *rank_of_surface, 
     original_index = std::move(idx);
 }
 
+std::string &last_error() {
+    thread_local std::string e;
+    return e;
+}
+
 }  // namespace heat
+
+// ---------------------------------------------------------------------------
+// Host-only entry points of the C ABI (include/heat_amd.h): no device needed.
+extern "C" {
+
+const char *heat_last_error(void) { return heat::last_error().c_str(); }
+int heat_amd_abi_version(void) { return HEAT_AMD_ABI_VERSION; }
+
+int heat_partition(const heat_batch_desc *desc, int32_t n_ranks, int32_t *rank_of_surface, int64_t *n_shared_zones) {
+    return heat::partition_surfaces(desc, n_ranks, rank_of_surface, n_shared_zones, heat::last_error());
+}
+
+int heat_plan_check(const heat_batch_desc *desc, const heat_batch_options *opt_in, int64_t summary[8]) {
+    heat_batch_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.device = -1;
+    opt.n_ranks = 1;
+    if (opt_in) opt = *opt_in;
+    heat::Plan p;
+    int rc = heat::make_plan(desc, opt, p, heat::last_error());
+    if (rc) return rc;
+    rc = heat::check_plan(p, desc, heat::last_error());
+    if (rc) return rc;
+    if (summary) {
+        int64_t n_blocks = 0, n_fast_tiles = 0;
+        for (int c = 0; c < heat::kNumFast; c++) {
+            n_fast_tiles += (int64_t)p.fast_tiles[c].size();
+            for (int g2 = 0; g2 < 4; g2++) n_blocks += (int64_t)p.fblocks[c][g2].size();
+        }
+        summary[0] = p.class_counts[0];
+        summary[1] = p.class_counts[1];
+        summary[2] = p.class_counts[2];
+        summary[3] = p.class_counts[3];
+        summary[4] = p.class_counts[4];
+        summary[5] = p.n_fused_surfaces;
+        summary[6] = n_blocks;
+        summary[7] = n_fast_tiles + (int64_t)p.gen_tiles.size();
+    }
+    return HEAT_OK;
+}
+
+}  // extern "C"

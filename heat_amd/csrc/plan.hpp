@@ -92,6 +92,9 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err);
 void find_clusters(const heat_batch_desc *d, std::vector<int32_t> &cluster_of_surface,
                    std::vector<int32_t> &cluster_of_zone, int32_t &n_clusters);
 
+// The message heat_last_error() returns (per thread).
+std::string &last_error();
+
 // heat_partition (include/heat_amd.h): rank of every surface, whole clusters kept together.
 int partition_surfaces(const heat_batch_desc *d, int32_t n_ranks, int32_t *rank_of_surface, int64_t *n_shared_zones,
                        std::string &err);

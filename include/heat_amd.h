@@ -251,6 +251,27 @@ int heat_batch_class_counts(const heat_batch *b, int64_t counts[5]);
 int heat_batch_set_timing(heat_batch *b, int32_t enabled);
 int heat_batch_get_timing(heat_batch *b, double *surf_us, double *substep_us, int64_t *n_samples);
 
+/*
+ * Partition of a model over the GPUs of a node (host-only: needs no device). Surfaces exchange heat only through
+ * the zones they face (model.rs:556-590), so a shard cut ALONG the zone-connected clusters shares no zone with
+ * another shard and needs no exchange at all; only a cluster heavier than a quarter of a shard (a whole building
+ * whose zones are all joined by interior walls) is cut by surface ranges, sharing zones at the cuts.
+ *   rank_of_surface[n_surfaces]   out: the rank every surface goes to, in [0, n_ranks); balanced by the algorithmic
+ *                                 bytes of the surfaces (32 n + 152), clusters kept in model order
+ *   n_shared_zones                out, nullable: zones faced by surfaces of more than one rank (0: no collective
+ *                                 is ever issued by the sharded march)
+ * heat_batch_create_shard builds the batch of one rank from the WHOLE model's descriptor and that partition
+ * (rank = opt->rank; zones, cavities and state slots stay global).
+ */
+int heat_partition(const heat_batch_desc *desc, int32_t n_ranks, int32_t *rank_of_surface, int64_t *n_shared_zones);
+int heat_batch_create_shard(const heat_batch_desc *desc, const heat_batch_options *opt, const int32_t *rank_of_surface,
+                            heat_batch **out);
+/* Host-only self-check of the planner (tests): plans `desc` as heat_batch_create_ex would and verifies the plan's
+ * internal consistency (every surface in exactly one tile, every index inside its array, every workgroup of the
+ * cluster-resident march inside the kernel's limits). summary (nullable): surfaces per kernel class [5], surfaces
+ * in the cluster-resident march, its workgroups, tiles. */
+int heat_plan_check(const heat_batch_desc *desc, const heat_batch_options *opt, int64_t summary[8]);
+
 const char *heat_last_error(void);
 int heat_amd_abi_version(void);
 
