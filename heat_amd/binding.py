@@ -99,8 +99,11 @@ SYMBOLS = [
     ("heat_batch_use_partials", C.c_int, [_H, C.c_void_p]),
     ("heat_batch_touched_zones", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("heat_batch_set_shared_zones", C.c_int, [_H, _i32p, C.c_int32]),
+    ("heat_comm_available", C.c_int, []),
     ("heat_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
     ("heat_batch_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
+    ("heat_batch_comm_init_ex", C.c_int, [_H, C.POINTER(C.c_uint8), _i32p, C.c_int32]),
+    ("heat_batch_set_owned_zones", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("heat_batch_n_shared_zones", C.c_int32, [_H]),
     ("heat_batch_set_fusion", C.c_int, [_H, C.c_int32]),
     ("heat_batch_n_fused_surfaces", C.c_int64, [_H]),
@@ -281,6 +284,11 @@ def plan_check(md, lib=None, **opts):
     return list(summary)
 
 
+def comm_available():
+    """Whether the library can load RCCL (no collective inside: vote on it before comm_init)."""
+    return load_library().heat_comm_available() == 0
+
+
 def comm_unique_id():
     """ncclGetUniqueId through the library (128 bytes). One rank calls it and hands the bytes to the others."""
     buf = (C.c_uint8 * 128)()
@@ -392,11 +400,21 @@ class HeatBatch:
         sz = np.ascontiguousarray(shared_zone, dtype=np.int32)
         _check(self._L.heat_batch_set_shared_zones(self._h, sz.ctypes.data_as(_i32p), len(sz)))
 
-    def comm_init(self, unique_id):
+    def comm_init(self, unique_id, extra_shared=None):
         """ncclCommInitRank with the 128-byte id of comm_unique_id() (collective: every rank calls it), then the
-        ranks agree on the shared zones. After it the batch marches like a single-GPU one."""
+        ranks agree on the shared zones (plus ``extra_shared``, tests). After it the batch marches like a
+        single-GPU one."""
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-        _check(self._L.heat_batch_comm_init(self._h, buf))
+        if extra_shared is None or len(extra_shared) == 0:
+            _check(self._L.heat_batch_comm_init(self._h, buf))
+        else:
+            ex = np.ascontiguousarray(extra_shared, dtype=np.int32)
+            _check(self._L.heat_batch_comm_init_ex(self._h, buf, ex.ctypes.data_as(_i32p), len(ex)))
+
+    def set_owned_zones(self, owned):
+        m = np.ascontiguousarray(owned, dtype=np.uint8)
+        assert len(m) == self.n_zones
+        _check(self._L.heat_batch_set_owned_zones(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     @property
     def n_shared_zones(self):

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -57,30 +58,45 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+struct RcclState {
+    Rccl r;
+    std::string err;
+    std::once_flag once;
+};
+RcclState &rccl_state() {
+    static RcclState st;
+    return st;
+}
+const std::string &rccl_error() { return rccl_state().err; }
+
 Rccl *rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void *h = nullptr;
-    for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
-    }
-    if (!h) return nullptr;
-    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
-    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
-    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString) {
-        dlclose(h);
-        return nullptr;
-    }
-    r.handle = h;
-    return &r;
+    RcclState &st = rccl_state();
+    std::call_once(st.once, [&st] {
+        Rccl &r = st.r;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+            const char *e = dlerror();  // (read once: dlerror() clears the message)
+            st.err = e ? e : "dlopen failed";
+        }
+        if (!h) return;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString) {
+            st.err = "symbols missing";
+            dlclose(h);
+            return;
+        }
+        st.err.clear();
+        r.handle = h;
+    });
+    return st.r.handle ? &st.r : nullptr;
 }
 
 #define RCCL_TRY(R, expr)                                                                             \
@@ -216,6 +232,10 @@ struct heat_batch {
     int n_shared = 0, n_touched = 0;
     DevBuf<int32_t> d_zlist, d_slot_of, d_shared_zone;
     std::vector<uint8_t> h_touched;
+    // Zones this batch finishes itself (unless they are shared with another rank): every zone on a single GPU; on a
+    // sharded batch the zones its surfaces face plus the zones NO rank faces that fall to it (z % n_ranks == rank) —
+    // such a zone still follows its a0 / b0 terms (heaters, infiltration: model.rs:410-423).
+    std::vector<uint8_t> h_owned;
     // library-owned collective (heat_batch_comm_init): RCCL communicator + the gathered partial blocks
     ncclComm_t comm = nullptr;
     DevBuf<double> d_gathered;  // [n_ranks][2][n_shared]
@@ -313,12 +333,6 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     b->n_smallcav_stream_tiles = b->n_smallcav_stream_tiles0 = p.n_smallcav_stream_tiles;
     b->any_fused = p.any_fused;
     b->h_zone_block = p.zone_block;
-    {
-        std::vector<int32_t> sz;
-        for (int64_t z = 0; z < Z; z++) if (b->h_zone_block[z] < 0) sz.push_back((int32_t)z);
-        b->n_stream_zones = (int)sz.size();
-        HIP_TRY(b->d_stream_zones.upload(sz));
-    }
     b->h_gen_tiles0 = b->h_gen_tiles_cur = p.gen_tiles;
     for (int c = 0; c < kNumFast; c++) {
         for (int g2 = 0; g2 < 4; g2++) {
@@ -339,6 +353,14 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_side_area.upload(p.side_area));
     HIP_TRY(b->d_side_lzone.upload(p.side_lzone));
     b->h_touched = p.touched;
+    b->h_owned = p.touched;
+    if (b->n_ranks <= 1) b->h_owned.assign(Z, 1);
+    {
+        std::vector<int32_t> sz;
+        for (int64_t z = 0; z < Z; z++) if (b->h_zone_block[z] < 0 && b->h_owned[z]) sz.push_back((int32_t)z);
+        b->n_stream_zones = (int)sz.size();
+        HIP_TRY(b->d_stream_zones.upload(sz));
+    }
 
     // ---- host copies used by download ----
     b->h_first_slot = std::move(p.h_first_slot);
@@ -567,6 +589,7 @@ void enqueue_zones(heat_batch *b, int mode) {
     const int32_t *zl = b->d_zlist.p;
     int nl = b->n_touched;
     if (mode == 3) { zl = b->d_stream_zones.p; nl = b->n_stream_zones; }
+    if (mode == 5) { mode = 3; }  // sharded batch, nothing fused in this call: every zone it owns (d_zlist), full update
     if (mode == 4) { zl = b->d_zlist_stream.p; nl = b->n_touched_stream; mode = 2; }  // sharded, beside a fused march
     launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_zone_contrib.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
@@ -745,7 +768,35 @@ int heat_batch_create_shard(const heat_batch_desc *desc, const heat_batch_option
             return fail(HEAT_E_SIZE, "surface %lld: rank %d outside [0, %d)", (long long)s, rank_of_surface[s], std::max(opt->n_ranks, 1));
     ShardDesc sh;
     sh.build(desc, rank_of_surface, opt->rank);
-    return heat_batch_create_ex(&sh.desc, opt, out);
+    int rc = heat_batch_create_ex(&sh.desc, opt, out);
+    if (rc) return rc;
+    heat_batch *b = *out;
+    // Zones by the ranks that face them: a zone nobody faces falls to rank z % n_ranks (it still follows a0 / b0,
+    // model.rs:410-423); when no zone is faced from two ranks the batch marches without any exchange.
+    const int64_t Z = desc->n_zones;
+    const int n_ranks = std::max(opt->n_ranks, 1);
+    std::vector<int32_t> first(Z, -1);
+    std::vector<uint8_t> shared(Z, 0), owned(Z, 0);
+    auto touch = [&](int32_t z, int32_t rk) {
+        if (first[z] < 0) first[z] = rk;
+        else if (first[z] != rk) shared[z] = 1;
+    };
+    for (int64_t s = 0; s < desc->n_surfaces; s++) {
+        if (desc->front_kind[s] == HEAT_BOUNDARY_SPACE) touch(desc->front_zone[s], rank_of_surface[s]);
+        if (desc->back_kind[s] == HEAT_BOUNDARY_SPACE) touch(desc->back_zone[s], rank_of_surface[s]);
+    }
+    int64_t n_shared = 0;
+    for (int64_t z = 0; z < Z; z++) {
+        n_shared += shared[z];
+        owned[z] = (first[z] < 0 && z % n_ranks == opt->rank) ? 1 : 0;
+    }
+    rc = heat_batch_set_owned_zones(b, owned.data());
+    if (!rc && n_ranks > 1 && n_shared == 0) rc = heat_batch_set_shared_zones(b, nullptr, 0);
+    if (rc) {
+        heat_batch_destroy(b);
+        *out = nullptr;
+    }
+    return rc;
 }
 
 void heat_batch_destroy(heat_batch *b) {
@@ -817,7 +868,8 @@ int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
         memcpy(state + b->h_first_slot[s], src + b->h_first_slot[s], (size_t)b->h_node_count[s] * sizeof(double));
         for (int a = 0; a < 4; a++) state[b->h_out_slots[a][s]] = src[b->h_out_slots[a][s]];
     }
-    for (int64_t z = 0; z < b->n_zones; z++) state[b->h_zone_slot_h[z]] = src[b->h_zone_slot_h[z]];
+    for (int64_t z = 0; z < b->n_zones; z++)
+        if (b->h_owned[z]) state[b->h_zone_slot_h[z]] = src[b->h_zone_slot_h[z]];
     return HEAT_OK;
 }
 
@@ -917,7 +969,7 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         if (sz[i] < 0 || sz[i] >= b->n_zones) return fail(HEAT_E_SIZE, "shared zone %d out of range", sz[i]);
         slot[sz[i]] = i;
     }
-    for (int64_t z = 0; z < b->n_zones; z++) if (b->h_touched[z]) zl.push_back((int32_t)z);
+    for (int64_t z = 0; z < b->n_zones; z++) if (b->h_owned[z]) zl.push_back((int32_t)z);
     HIP_TRY(b->d_slot_of.upload(slot));
     HIP_TRY(b->d_zlist.upload(zl));
     HIP_TRY(b->d_shared_zone.upload(sz));
@@ -999,7 +1051,7 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         std::vector<int32_t> szl, tz;
         for (int64_t z = 0; z < b->n_zones; z++) {
             b->h_zone_block[z] = zone_fused[z] ? 0 : -1;
-            if (!zone_fused[z]) szl.push_back((int32_t)z);
+            if (!zone_fused[z] && b->h_owned[z]) szl.push_back((int32_t)z);
         }
         b->n_stream_zones = (int)szl.size();
         HIP_TRY(b->d_stream_zones.upload(szl));
@@ -1017,10 +1069,15 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
     return HEAT_OK;
 }
 
+int heat_comm_available(void) {
+    if (rccl()) return HEAT_OK;
+    return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", rccl_error().c_str());
+}
+
 int heat_comm_unique_id(uint8_t id[HEAT_COMM_ID_BYTES]) {
     if (!id) return fail(HEAT_E_INVALID_ARG, "NULL argument");
     Rccl *r = rccl();
-    if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", rccl_error().c_str());
     static_assert(sizeof(ncclUniqueId) == HEAT_COMM_ID_BYTES, "ncclUniqueId size");
     ncclUniqueId u;
     RCCL_TRY(r, r->GetUniqueId(&u));
@@ -1028,11 +1085,35 @@ int heat_comm_unique_id(uint8_t id[HEAT_COMM_ID_BYTES]) {
     return HEAT_OK;
 }
 
+int heat_batch_set_owned_zones(heat_batch *b, const uint8_t *owned) {
+    if (!b || (!owned && b->n_zones > 0)) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    for (int64_t z = 0; z < b->n_zones; z++) b->h_owned[z] = (owned[z] || b->h_touched[z]) ? 1 : 0;
+    if (b->shared_set) {  // the zone lists follow
+        std::vector<int32_t> sz;
+        int rc = select_device(b);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy((sz.resize(b->n_shared), sz.data()), b->d_shared_zone.p, (size_t)b->n_shared * sizeof(int32_t),
+                          hipMemcpyDeviceToHost));
+        return heat_batch_set_shared_zones(b, sz.data(), b->n_shared);
+    }
+    std::vector<int32_t> szl;
+    for (int64_t z = 0; z < b->n_zones; z++)
+        if (b->h_zone_block[z] < 0 && b->h_owned[z]) szl.push_back((int32_t)z);
+    b->n_stream_zones = (int)szl.size();
+    HIP_TRY(b->d_stream_zones.upload(szl));
+    return HEAT_OK;
+}
+
 int heat_batch_comm_init(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES]) {
-    if (!b || !id) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    return heat_batch_comm_init_ex(b, id, nullptr, 0);
+}
+
+int heat_batch_comm_init_ex(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES], const int32_t *extra_shared,
+                            int32_t n_extra) {
+    if (!b || !id || n_extra < 0 || (n_extra > 0 && !extra_shared)) return fail(HEAT_E_INVALID_ARG, "bad argument");
     if (b->comm) return fail(HEAT_E_INVALID_ARG, "the batch already has a communicator");
     Rccl *r = rccl();
-    if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", rccl_error().c_str());
     int rc = select_device(b);
     if (rc) return rc;
     ncclUniqueId u;
@@ -1047,8 +1128,18 @@ int heat_batch_comm_init(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES]) {
     RCCL_TRY(r, r->AllReduce(d_mask.p, d_mask.p, mask.size(), ncclInt32, ncclSum, b->comm, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy(mask.data(), d_mask.p, mask.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> is_shared(std::max<int64_t>(Z, 1), 0);
+    for (int64_t z = 0; z < Z; z++) {
+        is_shared[z] = mask[z] >= 2;
+        // a zone no rank faces is finished by rank z % n_ranks (it still follows a0 / b0: model.rs:410-423)
+        b->h_owned[z] = (b->h_touched[z] || (mask[z] == 0 && z % b->n_ranks == b->rank)) ? 1 : 0;
+    }
+    for (int32_t i = 0; i < n_extra; i++) {  // zones the caller wants exchanged as well (tests, rehearsals)
+        if (extra_shared[i] < 0 || extra_shared[i] >= Z) return fail(HEAT_E_SIZE, "shared zone %d out of range", extra_shared[i]);
+        is_shared[extra_shared[i]] = 1;
+    }
     std::vector<int32_t> shared;
-    for (int64_t z = 0; z < Z; z++) if (mask[z] >= 2) shared.push_back((int32_t)z);
+    for (int64_t z = 0; z < Z; z++) if (is_shared[z]) shared.push_back((int32_t)z);
     return heat_batch_set_shared_zones(b, shared.data(), (int32_t)shared.size());
 }
 
@@ -1073,12 +1164,16 @@ int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_b
 int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_t n_sub, const double *zone_a0,
                               const double *zone_b0) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
-    if (b->n_ranks > 1 && !b->comm)
+    // A sharded batch needs a collective only for zones it shares with another rank: a partition along the clusters
+    // (heat_partition) shares none, and every rank then marches on its own.
+    const bool exchange = b->shared_set && b->n_shared > 0;
+    if (b->n_ranks > 1 && !b->comm && (exchange || !b->shared_set))
         return fail(HEAT_E_INVALID_ARG, "sharded batch without a communicator: call heat_batch_comm_init, or drive it "
-                                        "with heat_batch_step_surfaces / heat_batch_step_zones and your own collective");
+                                        "with heat_batch_step_surfaces / heat_batch_step_zones and your own collective "
+                                        "(a batch that shares no zone — heat_batch_set_shared_zones(b, NULL, 0) — needs neither)");
     int rc = heat_batch_set_weather(b, weather, n_sub, zone_a0, zone_b0);
     if (rc) return rc;
-    if (b->comm && b->shared_set) {
+    if (b->comm && exchange) {
         // Sharded sub-timestep, everything in order on the batch's stream (no cross-queue dependency anywhere):
         // this rank's surfaces -> zones only this rank touches finished, partial (a, b) of the shared zones ->
         // RCCL all-gather of the [2][n_shared] blocks over xGMI -> shared zones updated from the blocks, summed
@@ -1166,7 +1261,8 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
             b->ev_fused_pairs.push_back({e0, e1, n_sub});
         }
     }
-    const int zmode = fused ? 3 : 0;
+    // (a sharded batch finishes the zones it owns only; beside a cluster-resident march only the zones no workgroup owns)
+    const int zmode = fused ? 3 : (b->n_ranks > 1 ? 5 : 0);
     if (!streamed) {
         // nothing to stream
     } else if (b->timing) {

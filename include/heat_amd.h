@@ -212,10 +212,24 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
  *                         then the ranks agree on the shared zones (an all-reduce of the touched masks) and the
  *                         batch is switched to the compact exchange (as heat_batch_set_shared_zones does).
  * RCCL is loaded at run time (dlopen "librccl.so.1"); without it both calls return HEAT_E_COMM.
+ *   heat_comm_available   HEAT_OK when RCCL can be loaded (no collective inside: the ranks can vote on it BEFORE any
+ *                         of them enters the collective heat_batch_comm_init).
+ *   heat_batch_comm_init_ex  as heat_batch_comm_init, with extra_shared[n_extra] zones exchanged as well (the union
+ *                         with the agreed list; tests and single-GPU rehearsals of the exchange).
+ * Zones NO rank faces still follow their a0 / b0 terms (model.rs:410-423): rank z % n_ranks finishes zone z
+ * (heat_batch_comm_init and heat_batch_create_shard arrange that; heat_batch_set_owned_zones for callers that cut
+ * their shards themselves: owned[n_zones], OR-ed with the zones the batch's surfaces face).
+ * A sharded batch that shares no zone with another rank — a partition along the clusters, heat_partition —
+ * needs no communicator at all: after heat_batch_set_shared_zones(b, NULL, 0) (heat_batch_create_shard does it)
+ * heat_batch_march[_resident] run as on a single GPU, on the zones the batch owns.
  */
 #define HEAT_COMM_ID_BYTES 128
+int heat_comm_available(void);
 int heat_comm_unique_id(uint8_t id[HEAT_COMM_ID_BYTES]);
 int heat_batch_comm_init(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES]);
+int heat_batch_comm_init_ex(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES], const int32_t *extra_shared,
+                            int32_t n_extra);
+int heat_batch_set_owned_zones(heat_batch *b, const uint8_t *owned);
 int32_t heat_batch_n_shared_zones(const heat_batch *b);
 
 /*
