@@ -1,28 +1,38 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark of the MI355X wall heat-conduction path.
+"""bench.py — benchmark of the MI355X wall heat-conduction path.
 
-A *step* is one sub-timestep of ThermalModel::march (reference src/model.rs:369-424) over the
-whole batch: iterate_surfaces for every surface + the zone update. The workload is the
-north_star headline of BASELINE.json: 1 000 000 all-massive surfaces x 32 nodes per GPU
-(weak scaling: every rank holds its own million), RK4 + convection / long-wave / solar boundary
-updates, zones of 100 surfaces. State is resident in HBM when the timed region starts.
+A *step* is one sub-timestep of ThermalModel::march (reference src/model.rs:369-424) over the whole
+model: iterate_surfaces for every surface + the zone update. The default workload is the north_star
+headline of BASELINE.json — 1 000 000 all-massive surfaces x 32 nodes, RK4 + convection / long-wave /
+solar boundary updates, zones of 100 surfaces; `--config 2 | 3 | 5 | partitions` selects the other
+BASELINE configs. State is resident in HBM when the timed region starts.
 
-The K timed steps are issued as march calls of --substeps-per-march sub-timesteps each (default 20:
-a 15-minute model timestep at dt = 45 s), as ThermalModel::march runs its dt_subdivisions
-sub-timesteps per call. Inside one call the library keeps zone-connected clusters of surfaces
-resident on the chip (cluster-resident march, include/heat_amd.h); --no-fusion streams every
-sub-timestep through HBM instead, and a second, shorter leg always measures that streamed kernel
+The K timed steps are issued as march calls of --substeps-per-march sub-timesteps each (default 20: a
+15-minute model timestep at dt = 45 s), as ThermalModel::march runs its dt_subdivisions sub-timesteps
+per call. Inside one call the library keeps zone-connected clusters of surfaces resident on the chip
+(cluster-resident march, include/heat_amd.h) where its planner expects a gain; --no-fusion streams
+every sub-timestep through HBM instead, and a second, shorter leg always measures that streamed kernel
 (`roofline_streaming`) so that the per-sub-timestep HBM roofline stays on record.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      the surface kernel's algorithmic GB/s (HIP events on the kernel's stream, recorded
-                inside the timed region) against the 8 TB/s HBM3E peak;
-  cpu_baseline  the CPU oracle (oracle/, a C port of the reference path) timed on this box's host
-                cores on a bounded sample of the same workload (rank 0, N = 1 only).
+N > 1 (BASELINE config 4) shards the SAME model over the ranks ("scaling": "strong"): heat_partition cuts it
+along its zone-connected clusters, so that no zone is shared and no collective is issued (the headline; config 3's
+ring of zones is one cluster and is cut by surface ranges — its cut zones are exchanged with an RCCL all-gather per
+sub-timestep). `--scaling weak` gives every rank a model of its own with zones shared across the rank boundaries.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline            the dominant kernel against the resource that bounds it: "hbm" for a streamed march
+                      (algorithmic bytes / kernel time, HIP events on the kernel's stream, against 8 TB/s), "valu_issue"
+                      for a cluster-resident march (VALU wave-instructions per second, instruction count from the
+                      committed SQ counters, against SIMDs x clock / 4);
+  roofline_streaming  the streamed kernel's own line whenever the main run was cluster-resident;
+  cpu_baseline        the CPU oracle (oracle/, a C port of the reference path) timed on this box's host cores on a
+                      bounded sample of the same workload (rank 0, N = 1 only);
+  caller_owned        heat_batch_march on a caller-owned host state (the drop-in call of ThermalModel::march):
+                      PCIe-inclusive rate, never `value`.
 """
 import argparse
 import json
@@ -37,11 +47,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles each (16 lanes wide), 2.4 GHz peak engine clock
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # 1e9 wave-instructions per second
+
+CONFIGS = ("headline", "2", "3", "5", "partitions")
 
 
-def build_shard(S, n, zones_per_gpu, rank, world, dt, seed):
-    """This rank's million walls. Zones are global; zone boundaries are offset by half a zone so
-    that the first/last zone of every rank also has surfaces on the neighbouring rank."""
+def build_weak_shard(S, n, zones_per_gpu, rank, world, dt, seed):
+    """--scaling weak: this rank's own walls. Zones are global; zone boundaries are offset by half a zone so that
+    the first/last zone of every rank also has surfaces on the neighbouring rank (the exchange really runs)."""
     from heat_amd import modeldict as mdl
     Z = zones_per_gpu * world
     md, state = mdl.uniform_massive(S, n, Z=Z, dt=dt, seed=seed + rank)
@@ -52,59 +66,65 @@ def build_shard(S, n, zones_per_gpu, rank, world, dt, seed):
     return md, state
 
 
-CONFIGS = ("headline", "2", "3", "5", "partitions")
-
-
-def build_config(name, args, rank, world, dt, seed):
-    """The workloads of BASELINE.json / SURVEY.md §8(d). Returns (model dict, initial state, description)."""
+def build_config(name, args, dt, seed):
+    """The workloads of BASELINE.json / SURVEY.md §8(d), whole model. Returns (model dict, state, description)."""
     from heat_amd import modeldict as mdl
+    S = args.surfaces
     if name == "headline":
-        md, state = build_shard(args.surfaces, args.nodes, args.zones_per_gpu, rank, world, dt, seed)
-        return md, state, ("north_star headline: %d all-massive surfaces x %d nodes per GPU, RK4 + TARP convection + "
-                           "long-wave + solar boundaries, %d zones per GPU, dt = %g s" % (
-                               args.surfaces, args.nodes, args.zones_per_gpu, dt))
+        Z = max(1, S // 100)
+        md, state = mdl.uniform_massive(S, args.nodes, Z=Z, dt=dt, seed=seed)
+        return md, state, ("north_star headline: %d all-massive surfaces x %d nodes, RK4 + TARP convection + long-wave + "
+                           "solar boundaries, %d zones of 100 walls each (every zone a cluster of its own), dt = %g s"
+                           % (S, args.nodes, Z, dt))
     if name == "2":
         md, state = mdl.uniform_massive(10_000, 20, Z=100, dt=90.0, identical=True, vertical=True)
         return md, state, "BASELINE config 2: 10 000 identical 3-layer massive walls x 20 nodes, 100 zones, dt = 90 s"
     if name == "3":
-        S = args.surfaces
         md, state = mdl.ragged_mixed(S, Z=max(1, S // 100), dt=dt, seed=seed)
         return md, state, ("BASELINE config 3: %d ragged surfaces of 8-64 nodes (70 %% massive, 20 %% massive core "
                            "between no-mass facings, 10 %% two-node no-mass), mixed boundaries, %d zones joined in a "
-                           "ring by the Space/Space walls, dt = %g s" % (S, max(1, S // 100), dt))
+                           "ring by the Space/Space walls (one cluster), dt = %g s" % (S, max(1, S // 100), dt))
     if name == "5":
-        S = 200_000 if args.surfaces == 1_000_000 else args.surfaces
-        md, state = mdl.glazing_cavity(S, Z=max(1, S // 100), dt=dt)
+        S5 = 200_000 if S == 1_000_000 else S
+        md, state = mdl.glazing_cavity(S5, Z=max(1, S5 // 100), dt=dt)
         return md, state, ("BASELINE config 5: %d surfaces, half double glazing (4 no-mass nodes around a gas cavity), "
-                           "half Trombe-like (concrete / air cavity / glass, 17 nodes), dt = %g s" % (S, dt))
+                           "half Trombe-like (concrete / air cavity / glass, 17 nodes), dt = %g s" % (S5, dt))
+    if name == "partitions":
+        md, state = mdl.partitioned_buildings(S, args.nodes, dt=dt, seed=seed)
+        return md, state, ("buildings with interior partitions: %d all-massive walls x %d nodes in buildings of 8 rooms "
+                           "x 12 walls, 2 walls of every room are partitions to neighbouring rooms (front and back both "
+                           "Space, different zones): clusters of 8 zones, dt = %g s" % (S, args.nodes, dt))
     raise SystemExit("unknown --config %r" % name)
 
 
-def cpu_baseline(n, dt, seed, target_seconds=12.0):
-    """Times the oracle (single thread: the reference is single-threaded, model.rs:113-116) on a
-    bounded sample of the same workload."""
+def cpu_baseline(md_full, state_full, dt, target_seconds=12.0):
+    """Times the oracle (single thread: the reference is single-threaded, model.rs:113-116) on a bounded sample
+    of the same workload: the first surfaces of the model with their zones."""
     from heat_amd import modeldict as mdl
     from oracle import oracle as orc
-    S_cpu, steps = 20000, 10
-    md, state = mdl.uniform_massive(S_cpu, n, Z=S_cpu // 100, dt=dt, seed=seed)
+    S_all = int(md_full["n_surfaces"])
+    S_cpu = min(S_all, 20000)
+    md = mdl.subset(md_full, np.arange(S_cpu))
+    state = state_full.copy()
+    nodes = int(md["node_offset"][-1])
+    steps = 10
     m = orc.OracleModel(md)
     w = mdl.weather_series(steps, dt)
     t0 = time.perf_counter()
     rc, _ = m.march(state, w)
     t1 = time.perf_counter() - t0
     assert rc == 0
-    rate = S_cpu * n * steps / t1
-    # scale the sample up to ~target_seconds of CPU work
-    steps2 = int(max(steps, min(400, target_seconds * rate / (S_cpu * n))))
+    rate = nodes * steps / t1
+    steps2 = int(max(steps, min(400, target_seconds * rate / nodes)))
     w = mdl.weather_series(steps2, dt)
     t0 = time.perf_counter()
     rc, _ = m.march(state, w)
     t2 = time.perf_counter() - t0
     assert rc == 0
-    out = {"value": S_cpu * n * steps2 / t2, "unit": "node-updates/s", "cores": 1, "kind": "port",
-           "sample": "%d surfaces x %d nodes x %d sub-timesteps of the same workload, %.1f s; "
+    out = {"value": nodes * steps2 / t2, "unit": "node-updates/s", "cores": 1, "kind": "port",
+           "sample": "the first %d surfaces (%d nodes) of the same workload x %d sub-timesteps, %.1f s; "
                      "tri-diagonal storage, no per-step allocation: an upper bound on the Rust reference's speed"
-                     % (S_cpu, n, steps2, t2)}
+                     % (S_cpu, nodes, steps2, t2)}
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -112,34 +132,36 @@ def cpu_baseline(n, dt, seed, target_seconds=12.0):
     ncores = min(ncores, 16)  # the GPU box gives one GPU's share of the host: 16 cores
     if ncores > 1:
         st2 = state.copy()
+        half = max(1, steps2 // 2)
         t0 = time.perf_counter()
-        rc, _ = m.march(st2, w[:max(1, steps2 // 2)], threads=ncores)
+        rc, _ = m.march(st2, w[:half], threads=ncores)
         t3 = time.perf_counter() - t0
-        out["all_cores"] = {"value": S_cpu * n * max(1, steps2 // 2) / t3, "cores": ncores,
+        out["all_cores"] = {"value": nodes * half / t3, "cores": ncores,
                             "note": "OpenMP over surfaces = the reference's disabled rayon path (model.rs:113-116)"}
     return out
 
 
-def pmc_traffic(surfaces, nodes, mode="streamed", substeps=1):
-    """HBM bytes per launch of the surface kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; bench.py cannot run the profiler on itself). None when no
-    committed measurement matches this workload and kernel (mode: "streamed" = one sub-timestep per launch,
-    "fused" = `substeps` sub-timesteps per launch)."""
-    best = None
+def committed_counters(config, surfaces, nodes_total, mode, substeps=1):
+    """Counters of the surface kernel from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot run
+    the profiler on itself): the newest profiles/*_counters.json whose workload matches. Returns (dict, source)."""
+    best = (None, None)
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if f.endswith("_pmc_traffic.json"):
-            try:
-                j = json.load(open(os.path.join(pdir, f)))
-            except Exception:
-                continue
-            wl = j.get("workload", {})
-            if wl.get("surfaces") != surfaces or wl.get("nodes") != nodes or wl.get("mode", "streamed") != mode:
-                continue
-            if mode == "fused" and wl.get("substeps_per_launch") != substeps:
-                continue
-            best = (j["traffic_bytes_per_launch"], "profiles/" + f)
-    return best if best else (None, None)
+        if not f.endswith("_counters.json"):
+            continue
+        try:
+            j = json.load(open(os.path.join(pdir, f)))
+        except Exception:
+            continue
+        wl = j.get("workload", {})
+        if wl.get("config") != config or wl.get("surfaces") != surfaces or wl.get("mode") != mode:
+            continue
+        if wl.get("nodes_total") not in (None, nodes_total):
+            continue
+        if mode == "fused" and wl.get("substeps_per_launch") != substeps:
+            continue
+        best = (j, "profiles/" + f)
+    return best
 
 
 def march_in_calls(march, weather, per_call):
@@ -148,9 +170,19 @@ def march_in_calls(march, weather, per_call):
         march(weather[i:i + per_call])
 
 
+def hbm_roofline(ab, surf_us, substep_us, n, counters, src, kernel):
+    achieved = ab / (surf_us * 1e-6) / 1e9
+    traffic = counters.get("hbm_traffic_bytes_per_launch") if counters else None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "kernel": kernel,
+            "algorithmic_bytes_per_launch": ab, "kernel_us": surf_us, "substep_us": substep_us,
+            "frac_whole_sub_timestep": ab / (substep_us * 1e-6) / 1e9 / HBM_PEAK_GBS if substep_us else None,
+            "samples": n}
+
+
 def streaming_leg(md, state, args, dt, steps=60, warmup=10):
-    """The per-sub-timestep kernel on its own: a batch planned without the cluster-resident march
-    (16 nodes per lane, persistent waves), HIP events around every launch."""
+    """The per-sub-timestep kernels on their own: a batch planned without the cluster-resident march, HIP events
+    around every sub-timestep."""
     from heat_amd import HeatBatch, modeldict as mdl
     with HeatBatch(md, nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=True) as b:
         b.upload_state(state)
@@ -164,14 +196,12 @@ def streaming_leg(md, state, args, dt, steps=60, warmup=10):
         surf_us, substep_us, n = b.get_timing()
         ab = b.algorithmic_bytes
         counts = b.class_counts()
-    achieved = ab / (surf_us * 1e-6) / 1e9
-    traffic, src = pmc_traffic(args.surfaces, args.nodes, "streamed")
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src,
-            "kernel": "k_surfaces_fast<M,...,0> (iterate_surfaces, one sub-timestep per launch, state streamed through HBM)",
-            "algorithmic_bytes_per_launch": ab, "kernel_us": surf_us, "substep_us": substep_us, "samples": n,
-            "node_updates_per_sec": int(md["node_offset"][-1]) * steps / el,
-            "kernel_classes[M4,M8,M16,small,general]": counts}
+    counters, src = committed_counters(args.config, int(md["n_surfaces"]), int(md["node_offset"][-1]), "streamed")
+    r = hbm_roofline(ab, surf_us, substep_us, n, counters, src,
+                     "streamed march: iterate_surfaces, one sub-timestep per launch, state streamed through HBM")
+    r["node_updates_per_sec"] = int(md["node_offset"][-1]) * steps / el
+    r["kernel_classes[M4,M8,M16,small,general]"] = counts
+    return r
 
 
 def main():
@@ -181,9 +211,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=CONFIGS, default="headline",
                     help="workload: the north_star headline (default) or a BASELINE.json config")
-    ap.add_argument("--surfaces", type=int, default=1_000_000, help="surfaces per GPU")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: shard the same model (BASELINE config 4; default) or give every rank its own")
+    ap.add_argument("--surfaces", type=int, default=1_000_000, help="surfaces of the model (weak scaling: per GPU)")
     ap.add_argument("--nodes", type=int, default=32)
-    ap.add_argument("--zones-per-gpu", type=int, default=10_000)
     ap.add_argument("--nodes-per-lane", type=int, default=0)
     ap.add_argument("--no-palette", action="store_true", help="keep dt/mass and U as per-node arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,6 +223,8 @@ def main():
     ap.add_argument("--no-fusion", action="store_true",
                     help="stream every sub-timestep through HBM (no cluster-resident march)")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the second leg that measures the streamed kernel")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the caller-owned-state and sub-timesteps-per-call measurements")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
@@ -216,19 +249,29 @@ def main():
     K, W = args.steps, args.warmup
     dt = 45.0
     seed = 20260401
+    weak = args.scaling == "weak" and (world > 1 or args.force_sharded or args.force_shared_zones > 0)
 
     from heat_amd import HeatBatch, modeldict as mdl
-    md, state, workload = build_config(args.config, args, rank, world, dt, seed)
+    if weak:
+        if args.config != "headline":
+            raise SystemExit("--scaling weak exists for the headline workload only")
+        md, state = build_weak_shard(args.surfaces, args.nodes, max(1, args.surfaces // 100), rank, world, dt, seed)
+        workload = ("north_star headline, weak scaling: %d all-massive surfaces x %d nodes PER GPU, zones of 100 walls "
+                    "offset by half a zone against the rank boundaries, dt = %g s" % (args.surfaces, args.nodes, dt))
+    else:
+        md, state, workload = build_config(args.config, args, dt, seed)
     dt = float(md["dt"])
-    n_nodes_local = int(md["node_offset"][-1])
+    n_nodes_model = int(md["node_offset"][-1])
     weather_w = mdl.weather_series(max(W, 1), dt)
     weather_k = mdl.weather_series(K, dt, t0=dt * W)
 
     sharded = world > 1 or args.force_sharded or args.force_shared_zones > 0
+    n_shared_partition = None
+    sm = None
     if sharded:
         import torch
         import torch.distributed as dist
-        from heat_amd.sharded import ShardedMarch
+        from heat_amd.sharded import ShardedMarch, partition_model
         torch.cuda.set_device(local_rank)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -236,9 +279,15 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         forced = None
         if args.force_shared_zones > 0:
-            forced = np.unique(np.linspace(0, args.zones_per_gpu * world - 1, args.force_shared_zones).astype(np.int32))
+            forced = np.unique(np.linspace(0, int(md["n_zones"]) - 1, args.force_shared_zones).astype(np.int32))
+        ranks = None
+        if not weak:
+            # every rank cuts the same model the same way (host-only, deterministic): whole clusters per rank
+            ranks, n_shared_partition = partition_model(md, world)
         sm = ShardedMarch(md, rank, world, device_index=local_rank, collective=args.collective, force_shared=forced,
-                          nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=args.no_fusion)
+                          rank_of_surface=ranks, n_shared_in_partition=n_shared_partition,
+                          nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=args.no_fusion,
+                          use_graph=True)
         batch = sm.batch
         batch.upload_state(state)
 
@@ -277,12 +326,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    algorithmic_bytes = batch.algorithmic_bytes
+    algorithmic_bytes = batch.algorithmic_bytes      # of this rank's batch
     counts = batch.class_counts()
     n_fused = batch.n_fused_surfaces if not args.no_fusion else 0
-    fused = n_fused > 0
-    total_nodes = n_nodes_local * world
+    n_local_surfaces = batch.n_surfaces_in_batch
+    fused = n_fused > 0 and P >= (1 if n_local_surfaces <= 8192 else 3)
+    total_nodes = n_nodes_model * (world if weak else 1)
     value = total_nodes * K / elapsed
+    if sharded:
+        n_shared = batch.n_shared_zones
+        how = {"native": "library-owned RCCL communicator, all-gather in the batch's one stream",
+               "torch": "torch.distributed.all_gather_into_tensor", "none": "no collective issued"}[sm.collective]
+        parallelism = ("surfaces sharded %d-way %s, zones replicated; %d zones shared between ranks (%s)" % (
+            world, "by rank-local models" if weak else "along the zone-connected clusters (heat_partition)", n_shared, how))
+    else:
+        n_shared = 0
+        parallelism = "single GPU"
     result = {
         "metric": "surface-node-updates/sec",
         "value": value,
@@ -292,7 +351,7 @@ def main():
         "warmup": W,
         "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if weak else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -300,42 +359,79 @@ def main():
         "config": {
             "workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
             "config": args.config,
-            "surfaces_per_gpu": int(md["n_surfaces"]), "nodes_per_gpu": n_nodes_local,
-            "zones_per_gpu": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
-            "kernel_classes[M4,M8,M16,small,general]": counts,
-            "surfaces_in_cluster_resident_march": n_fused,
-            "parallelism": "surfaces sharded %d-way, zones replicated, per-sub-timestep RCCL all-gather of the partial "
-                           "sums of %d shared zones (%s)" % (
-                               world, sm.n_shared_zones,
-                               "library-owned communicator, one stream" if args.collective == "native" else "torch.distributed")
-            if sharded else "single GPU",
+            "surfaces": int(md["n_surfaces"]) * (world if weak else 1), "nodes": total_nodes,
+            "zones": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
+            "surfaces_on_rank0": n_local_surfaces,
+            "kernel_classes_rank0[M4,M8,M16,small,general]": counts,
+            "surfaces_in_cluster_resident_march_rank0": n_fused,
+            "n_shared_zones": n_shared,
+            "parallelism": parallelism,
         },
     }
-    if n_samples > 0:
-        # algorithmic bytes of a launch = SURVEY.md §8(d)'s 32 n + 152 bytes per surface and sub-timestep x the
-        # sub-timesteps the launch marches (1 streamed; P cluster-resident)
-        per_launch = P if fused else 1
-        achieved = algorithmic_bytes / (surf_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic(args.surfaces, args.nodes, "fused" if fused else "streamed", per_launch)
-        result["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": ("k_surfaces_fast<M,...,FUSED> (cluster-resident march: %d sub-timesteps of iterate_surfaces + zone "
-                       "update per launch, node temperatures in registers; the streamed kernel's own line is "
-                       "roofline_streaming)" % P) if fused else
-                      "k_surfaces_fast (iterate_surfaces: RK4 stencil + boundary updates, one sub-timestep per launch)",
-            "sub_timesteps_per_launch": per_launch,
-            "algorithmic_bytes_per_launch": algorithmic_bytes * per_launch,
-            "kernel_us": surf_us * per_launch, "kernel_us_per_sub_timestep": surf_us, "substep_us": substep_us,
-            "samples": n_samples,
-            "note": ("frac > 1 is possible: the launch re-uses the state on chip instead of streaming it per "
-                     "sub-timestep, so its HBM traffic is far below the algorithmic (streaming) byte count") if fused else None,
-        }
-    if rank == 0 and world == 1 and fused and not args.no_streaming_leg:
+    nodes_local = batch.n_nodes
+    if n_samples > 0 and fused:
+        # The cluster-resident march re-uses the state on chip: its HBM traffic is a small fraction of the
+        # streaming byte count, and what bounds it is VALU issue. achieved = VALU wave-instructions per second, with
+        # the instruction count per tile and sub-timestep from the committed SQ counters of this workload.
+        counters, src = committed_counters(args.config, int(md["n_surfaces"]), n_nodes_model, "fused", P)
+        rl = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+              "kernel": "k_surfaces_fast<M,...,FUSED> (cluster-resident march: %d sub-timesteps of iterate_surfaces + zone "
+                        "balance per launch, node temperatures in registers)" % P,
+              "sub_timesteps_per_launch": P, "kernel_us": surf_us * P, "kernel_us_per_sub_timestep": surf_us,
+              "substep_us": substep_us, "samples": n_samples, "counters_source": src,
+              "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction"}
+        if counters:
+            valu = counters["valu_insts_per_launch"] * (nodes_local / counters["workload"]["nodes_total"]) / counters["workload"]["substeps_per_launch"]
+            rl["achieved"] = valu / (surf_us * 1e-6) / 1e9
+            rl["frac"] = rl["achieved"] / VALU_PEAK_GINST
+            rl["valu_insts_per_sub_timestep"] = valu
+            rl["traffic"] = counters.get("hbm_traffic_bytes_per_launch")
+            if rl["traffic"]:
+                rl["hbm_gbs_measured_traffic"] = rl["traffic"] / (surf_us * P * 1e-6) / 1e9
+                rl["hbm_frac_measured_traffic"] = rl["hbm_gbs_measured_traffic"] / HBM_PEAK_GBS
+        else:
+            rl["achieved"] = rl["frac"] = rl["traffic"] = None
+        rl["equivalent_streaming_gbs"] = algorithmic_bytes / (surf_us * 1e-6) / 1e9
+        rl["equivalent_streaming_note"] = ("algorithmic (streaming) bytes of the same sub-timesteps / kernel time: what a "
+                                           "streamed march would have to sustain; not a roofline fraction")
+        result["roofline"] = rl
+    elif n_samples > 0:
+        counters, src = committed_counters(args.config, int(md["n_surfaces"]), n_nodes_model, "streamed")
+        result["roofline"] = hbm_roofline(algorithmic_bytes, surf_us, substep_us, n_samples, counters, src,
+                                          "streamed march: k_surfaces_stream / k_surfaces_fast (iterate_surfaces: RK4 stencil "
+                                          "+ boundary updates, one sub-timestep per launch)")
+    extras = rank == 0 and world == 1 and not sharded and not args.no_extras
+    if extras:
+        # the drop-in call on a caller-owned host state (PCIe-inclusive; never `value`)
+        st = state.copy()
+        wcall = mdl.weather_series(P, dt)
+        batch.march(st, wcall)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            batch.march(st, wcall)
+        tc = (time.perf_counter() - t0) / reps
+        result["caller_owned"] = {"value": n_nodes_model * P / tc, "unit": "node-updates/s", "ms_per_call": tc * 1e3,
+                                  "sub_timesteps_per_call": P, "state_megabytes": st.nbytes / 1e6,
+                                  "note": "heat_batch_march: inputs up, march, outputs down, caller's pageable numpy array"}
+        # how the sub-timesteps per march call change the picture (the reference's config 1 runs 2 per call)
+        sens = {}
+        for p in (2, 5, 20):
+            wv = mdl.weather_series(p, dt)
+            calls = max(2, 40 // p)
+            batch.march_resident(wv)
+            batch.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                batch.march_resident(wv)
+            batch.synchronize()
+            sens[str(p)] = n_nodes_model * p * calls / (time.perf_counter() - t0)
+        result["value_by_substeps_per_march"] = sens
+    if rank == 0 and world == 1 and not sharded and fused and not args.no_streaming_leg:
         batch.close()
         result["roofline_streaming"] = streaming_leg(md, state, args, dt)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.nodes, dt, seed)
+        result["cpu_baseline"] = cpu_baseline(md, state, dt)
     if sharded:
         import torch.distributed as dist
         sm.close()

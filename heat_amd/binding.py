@@ -142,7 +142,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB
+    # HEAT_AMD_LIB: another build of the same sources (measurement variants); the default is the in-tree library
+    return os.environ.get("HEAT_AMD_LIB") or _build.LIB
 
 
 def build_library(force=False):
@@ -439,6 +440,11 @@ class HeatBatch:
         a, b, n = _d(0), _d(0), C.c_int64(0)
         _check(self._L.heat_batch_get_timing(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    @property
+    def n_surfaces_in_batch(self):
+        """Surfaces this batch holds (a shard of the model when created with rank_of_surface)."""
+        return int(self._L.heat_batch_n_surfaces(self._h))
 
     @property
     def algorithmic_bytes(self):

@@ -215,6 +215,29 @@ def uniform_massive(S, n, Z=None, dt=45.0, seed=20260401, identical=False, verti
     return md, state
 
 
+def partitioned_buildings(S, n, rooms=8, walls_per_room=12, partitions_per_room=2, dt=45.0, seed=20260401):
+    """Buildings as real models have them: `rooms` zones per building, every room with `walls_per_room` all-massive
+    walls of n nodes, `partitions_per_room` of which are interior partitions to the next room of the same building
+    (front AND back face a Space, in different zones: src/model.rs:556-590 adds such a wall to both zones). The
+    zones of a building form one cluster; buildings are independent of each other."""
+    per_building = rooms * walls_per_room
+    S = max(per_building, S // per_building * per_building)
+    B = S // per_building
+    Z = B * rooms
+    md, state = uniform_massive(S, n, Z=Z, dt=dt, seed=seed)
+    s = np.arange(S, dtype=np.int64)
+    room = s // walls_per_room                       # global room (zone) number: rooms of a building are consecutive
+    w = s % walls_per_room
+    building = room // rooms
+    nxt = building * rooms + (room % rooms + 1) % rooms
+    part = w < partitions_per_room
+    md["back_zone"] = room.astype(np.int32)
+    md["front_zone"] = np.where(part, nxt, room).astype(np.int32)
+    md["front_kind"] = np.where(part, SPACE, OUTDOOR).astype(np.int32)
+    set_ir_from_air(md, state, 10.0)
+    return md, state
+
+
 def _draw_materials(rng, S, dt):
     """k in U[0.03,2], rho*cp in U[4e4,2.5e6], dx in U[0.005,0.04], re-drawn until the reference's
     Euler bound (discretization.rs:453-465, evaluated at 2*dt because the model halves it, model.rs:328-331) holds."""

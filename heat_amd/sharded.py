@@ -39,6 +39,39 @@ def shard_model(md, rank, n_ranks):
     return mdl.subset(md, np.arange(b[rank], b[rank + 1]))
 
 
+def partition_model(md, n_ranks):
+    """heat_partition (host-only, include/heat_amd.h): rank of every surface, whole zone-connected clusters kept
+    together — and the number of zones that still end up shared (0: the sharded march needs no collective)."""
+    from . import binding
+    return binding.partition(md, n_ranks)
+
+
+def shard_by_ranks(md, ranks, rank):
+    """Model dict of the surfaces ``ranks == rank``; zones, state slots and n_state stay global."""
+    from . import modeldict as mdl
+    return mdl.subset(md, np.nonzero(np.asarray(ranks) == rank)[0])
+
+
+def touched_mask(md_shard):
+    """What heat_batch_touched_zones reports for a shard: 1 for every zone one of its surfaces faces."""
+    from . import modeldict as mdl
+    t = np.zeros(int(md_shard["n_zones"]), dtype=np.uint8)
+    t[np.asarray(md_shard["front_zone"])[np.asarray(md_shard["front_kind"]) == mdl.SPACE]] = 1
+    t[np.asarray(md_shard["back_zone"])[np.asarray(md_shard["back_kind"]) == mdl.SPACE]] = 1
+    return t
+
+
+def zone_roles(touch_count, local_mask, rank, n_ranks):
+    """From the all-reduced touch counts: (shared zones — faced from two ranks or more, the only ones exchanged;
+    owned mask — zones this rank finishes: those it faces plus, of the zones NO rank faces, every n_ranks-th one:
+    such a zone still follows its a0 / b0 terms, reference src/model.rs:410-423)."""
+    cnt = np.asarray(touch_count)
+    z = np.arange(len(cnt))
+    shared = np.nonzero(cnt >= 2)[0].astype(np.int32)
+    owned = (np.asarray(local_mask) != 0) | ((cnt == 0) & (z % n_ranks == rank))
+    return shared, owned.astype(np.uint8)
+
+
 def shared_zones(touched_masks):
     """touched_masks: [n_ranks, n_zones] 0/1. Returns the sorted global numbers of the zones that more than one
     rank touches (the only zones whose heat balance needs an exchange)."""
@@ -71,22 +104,33 @@ class ZoneExchange:
         return self.gathered
 
 
-def agree_on_shared_zones(local_mask, device, group=None):
-    """Every rank contributes its touched-zone mask; all get the same shared-zone list."""
+def agree_on_zones(local_mask, device, group=None):
+    """Every rank contributes its touched-zone mask; all get the same shared-zone list, and each its owned mask
+    (zone_roles)."""
     import torch
     import torch.distributed as dist
     m = torch.as_tensor(np.asarray(local_mask, dtype=np.int32), device=device)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
-        return np.nonzero(m.cpu().numpy() >= 2)[0].astype(np.int32)
-    return np.zeros(0, dtype=np.int32)
+        return zone_roles(m.cpu().numpy(), local_mask, dist.get_rank(group), dist.get_world_size(group))
+    return np.zeros(0, dtype=np.int32), np.ones(len(local_mask), dtype=np.uint8)
+
+
+def agree_on_shared_zones(local_mask, device, group=None):
+    """The shared-zone list alone (agree_on_zones)."""
+    return agree_on_zones(local_mask, device, group)[0]
 
 
 class ShardedMarch:
-    """Drives one rank's HeatBatch through the sharded sub-timestep with the zone exchange."""
+    """Drives one rank's HeatBatch through the sharded sub-timestep with the zone exchange.
 
-    def __init__(self, md_shard, rank, n_ranks, device_index=0, collective="native", force_shared=None,
-                 **batch_opts):
+    ``md`` is this rank's shard — or, with ``rank_of_surface`` (partition_model), the WHOLE model, from which the
+    library picks the rank's surfaces (heat_batch_create_shard). A partition that shares no zone (``n_shared == 0``
+    from partition_model, the usual case: clusters are kept whole) needs no communicator and no collective at all:
+    every rank marches its clusters on its own (``collective`` ends up "none")."""
+
+    def __init__(self, md, rank, n_ranks, device_index=0, collective="native", force_shared=None,
+                 rank_of_surface=None, n_shared_in_partition=None, **batch_opts):
         import sys
         from . import binding
         if binding._lib is not None and "torch" not in sys.modules:
@@ -95,7 +139,7 @@ class ShardedMarch:
                 "cannot share a device in one process. Import torch before creating the first HeatBatch.")
         import torch
         import torch.distributed as dist
-        from .binding import HeatBatch, comm_unique_id
+        from .binding import HeatBatch, comm_available, comm_unique_id
         if collective not in ("native", "torch"):
             raise ValueError("collective must be 'native' or 'torch'")
         self.torch = torch
@@ -107,44 +151,48 @@ class ShardedMarch:
         # torch orders its own collective against it (the legacy default stream has handle 0, which the C ABI
         # reads as "create your own stream").
         self.stream = torch.cuda.Stream(device=device_index)
-        self.batch = HeatBatch(md_shard, device=device_index, stream=self.stream.cuda_stream, n_ranks=n_ranks,
-                               rank=rank, **batch_opts)
+        self.batch = HeatBatch(md, device=device_index, stream=self.stream.cuda_stream, n_ranks=n_ranks,
+                               rank=rank, rank_of_surface=rank_of_surface, **batch_opts)
+        self.shared = None
+        self.exchange = None
+        forced = None if force_shared is None or len(force_shared) == 0 else np.asarray(force_shared, dtype=np.int32)
+        if rank_of_surface is not None and n_shared_in_partition == 0 and forced is None:
+            # heat_batch_create_shard has seen that no zone is faced from two ranks: nothing to exchange, ever
+            self.collective = "none"
+            return
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        on_dev = multi and dist.get_backend() == "nccl"
         if collective == "native":
-            # rank 0 draws the RCCL unique id; torch.distributed only carries its 128 bytes to the others
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
-            if dist.is_initialized() and dist.get_world_size() > 1:
-                on_dev = dist.get_backend() == "nccl"
-                t = uid.to(dev) if on_dev else uid
-                dist.broadcast(t, src=0)
-                uid = t.cpu()
-            ok, why = 1, ""
-            try:
-                self.batch.comm_init(uid.numpy().tobytes())
-            except binding.HeatError as e:  # RCCL not loadable / communicator refused: every rank must learn of it
-                ok, why = 0, str(e)
-            if dist.is_initialized() and dist.get_world_size() > 1:
-                t = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            # The ranks vote on RCCL BEFORE any of them enters the collective ncclCommInitRank: a rank that cannot
+            # load it would leave the others waiting inside.
+            ok = 1 if comm_available() else 0
+            if multi:
+                t = torch.tensor([ok], dtype=torch.int32, device=dev if on_dev else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 ok = int(t.item())
-            if not ok:
-                print("heat_amd: library-owned communicator unavailable (%s); using torch.distributed for the "
-                      "zone exchange" % (why or "another rank failed"), file=sys.stderr)
-                collective = self.collective = "torch"
-        if collective == "native":
-            self.shared = None  # agreed inside the library
-            if force_shared is not None:
-                self.batch.set_shared_zones(np.asarray(force_shared, dtype=np.int32))
-            self.exchange = None
-        else:
-            self.shared = agree_on_shared_zones(self.batch.touched_zones(), dev)
-            if force_shared is not None:
-                # tests / single-GPU rehearsal: treat these zones as shared although no other rank touches them
-                self.shared = np.union1d(self.shared, np.asarray(force_shared, dtype=np.int32)).astype(np.int32)
-            self.batch.set_shared_zones(self.shared)
-            self.exchange = ZoneExchange(len(self.shared), dev)
-            self.batch.use_partials(self.exchange.partial.data_ptr())
+            if ok:
+                # rank 0 draws the RCCL unique id; torch.distributed only carries its 128 bytes to the others
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
+                if multi:
+                    t = uid.to(dev) if on_dev else uid
+                    dist.broadcast(t, src=0)
+                    uid = t.cpu()
+                # the zones the ranks share are agreed inside (plus the forced ones: the union, on every rank)
+                self.batch.comm_init(uid.numpy().tobytes(), extra_shared=forced)
+                return
+            print("heat_amd: RCCL cannot be loaded on every rank; using torch.distributed for the zone exchange",
+                  file=sys.stderr)
+            self.collective = "torch"
+        self.shared, owned = agree_on_zones(self.batch.touched_zones(), dev)
+        if forced is not None:
+            # tests / single-GPU rehearsal: treat these zones as shared although no other rank touches them
+            self.shared = np.union1d(self.shared, forced).astype(np.int32)
+        self.batch.set_owned_zones(owned)
+        self.batch.set_shared_zones(self.shared)
+        self.exchange = ZoneExchange(len(self.shared), dev)
+        self.batch.use_partials(self.exchange.partial.data_ptr())
 
     @property
     def n_shared_zones(self):
@@ -153,7 +201,7 @@ class ShardedMarch:
     def march_resident(self, weather, zone_a0=None, zone_b0=None):
         """≙ ThermalModel::march on the device-resident state of this shard (asynchronous)."""
         b = self.batch
-        if self.collective == "native":
+        if self.collective in ("native", "none"):
             b.march_resident(weather, zone_a0, zone_b0)
             return
         with self.torch.cuda.stream(self.stream):

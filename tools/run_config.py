@@ -10,8 +10,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 mode = sys.argv[4] if len(sys.argv) > 4 else "plan"
 S = int(sys.argv[5]) if len(sys.argv) > 5 else 1_000_000
 npl = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-args = types.SimpleNamespace(surfaces=S, nodes=32, zones_per_gpu=S // 100)
-md, st, desc = bench.build_config(cfg, args, 0, 1, 45.0, 20260401)
+args = types.SimpleNamespace(surfaces=S, nodes=32)
+md, st, desc = bench.build_config(cfg, args, 45.0, 20260401)
 dt = float(md["dt"])
 w = mdl.weather_series(P, dt)
 with HeatBatch(md, use_graph=True, no_fusion=(mode == "stream"), nodes_per_lane=npl) as b:
