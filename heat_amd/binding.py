@@ -90,8 +90,11 @@ SYMBOLS = [
     ("heat_batch_download_state", C.c_int, [_H, _dp, C.c_size_t]),
     ("heat_batch_upload_inputs", C.c_int, [_H, _dp, C.c_size_t]),
     ("heat_batch_march", C.c_int, [_H, _dp, C.c_size_t, C.POINTER(Weather), C.c_int32, _dp, _dp]),
+    ("heat_batch_march_ex", C.c_int, [_H, _dp, C.c_size_t, C.POINTER(Weather), C.c_int32, _dp, _dp, C.c_int32]),
+    ("heat_batch_download_outputs", C.c_int, [_H, _dp, C.c_size_t, C.c_int32]),
     ("heat_batch_march_resident", C.c_int, [_H, C.POINTER(Weather), C.c_int32, _dp, _dp]),
     ("heat_batch_synchronize", C.c_int, [_H]),
+    ("heat_batch_failed_surface", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("heat_batch_set_weather", C.c_int, [_H, C.POINTER(Weather), C.c_int32, _dp, _dp]),
     ("heat_batch_step_surfaces", C.c_int, [_H, C.c_int32]),
     ("heat_batch_step_zones", C.c_int, [_H, C.c_void_p, C.c_int32]),
@@ -358,12 +361,21 @@ class HeatBatch:
     def download_state(self, state):
         _check(self._L.heat_batch_download_state(self._h, self._state_ptr(state), state.size))
 
-    def march(self, state, weather, zone_a0=None, zone_b0=None):
-        """≙ ThermalModel::march: len(weather) sub-timesteps, in place on ``state``."""
+    OUT_NODES, OUT_SCALARS, OUT_ZONES, OUT_ALL = 1, 2, 4, 7
+
+    def march(self, state, weather, zone_a0=None, zone_b0=None, outputs=None):
+        """≙ ThermalModel::march: len(weather) sub-timesteps, in place on ``state``. ``outputs``: which of this
+        path's outputs are written back (OUT_* bits; default all)."""
         w, n = as_weather(weather)
         a0, pa = self._opt(zone_a0)
         b0, pb = self._opt(zone_b0)
-        _check(self._L.heat_batch_march(self._h, self._state_ptr(state), state.size, w, n, pa, pb))
+        if outputs is None:
+            _check(self._L.heat_batch_march(self._h, self._state_ptr(state), state.size, w, n, pa, pb))
+        else:
+            _check(self._L.heat_batch_march_ex(self._h, self._state_ptr(state), state.size, w, n, pa, pb, int(outputs)))
+
+    def download_outputs(self, state, outputs):
+        _check(self._L.heat_batch_download_outputs(self._h, self._state_ptr(state), state.size, int(outputs)))
 
     def march_resident(self, weather, zone_a0=None, zone_b0=None):
         w, n = as_weather(weather)
@@ -373,6 +385,12 @@ class HeatBatch:
 
     def synchronize(self):
         _check(self._L.heat_batch_synchronize(self._h))
+
+    def failed_surface(self):
+        """(index, kind) of the first place the last reported numerical failure was seen; (-1, 0) if none."""
+        i, k = C.c_int64(-1), C.c_int32(0)
+        _check(self._L.heat_batch_failed_surface(self._h, C.byref(i), C.byref(k)))
+        return int(i.value), int(k.value)
 
     def set_weather(self, weather, zone_a0=None, zone_b0=None):
         w, n = as_weather(weather)

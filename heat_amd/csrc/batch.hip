@@ -23,6 +23,7 @@
 #include "../../include/heat_amd.h"
 #include "kernels.hpp"
 #include "layout.hpp"
+#include "hostpool.hpp"
 #include "plan.hpp"
 
 using namespace heat;
@@ -231,6 +232,9 @@ struct heat_batch {
     bool shared_set = false;
     int n_shared = 0, n_touched = 0;
     DevBuf<int32_t> d_zlist, d_slot_of, d_shared_zone;
+    std::vector<int64_t> h_orig_of;  // device surface -> surface of the caller's descriptor
+    int64_t fail_index = -1;         // where the last reported numerical failure happened first (heat_batch_failed_surface)
+    int32_t fail_kind = 0;
     std::vector<uint8_t> h_touched;
     // Zones this batch finishes itself (unless they are shared with another rank): every zone on a single GPU; on a
     // sharded batch the zones its surfaces face plus the zones NO rank faces that fall to it (z % n_ranks == rank) —
@@ -248,6 +252,20 @@ struct heat_batch {
     double *h_zone_ab = nullptr;       // pinned, [2][n_zones]
     size_t weather_cap = 0;
     int n_weather = 0;
+
+    // heat_batch_march on a caller-owned state: compact transfers through pinned staging, host gathers / scatters
+    // on a thread pool ("Data at the boundary")
+    std::vector<int64_t> h_in_slots;   // [4][S] in device surface order: solar_f, solar_b, ir_f, ir_b
+    std::vector<int64_t> h_node_off;   // [S + 1] node offsets in the caller's surface order
+    DevBuf<double> d_compact;          // inputs [4 S + Z]; outputs [N nodes | 4 S scalars | Z zones]
+    DevBuf<int64_t> d_compact_off;     // per device surface: where its nodes go in the compact output
+    DevBuf<int32_t> d_orig_of32;
+    double *h_pin = nullptr;           // pinned staging
+    size_t pin_doubles = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    std::vector<std::pair<int64_t, int64_t>> out_chunks;  // surface ranges of the node part, a staging half each
+    HostPool *pool = nullptr;
 
     // host copies for download (original surface order)
     std::vector<int64_t> h_first_slot, h_node_count, h_out_slots[4], h_zone_slot_h;
@@ -281,6 +299,10 @@ struct heat_batch {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
         for (auto e : ev_pool) (void)hipEventDestroy(e);
+        delete pool;
+        if (h_pin) (void)hipHostFree(h_pin);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (auto e : ev_copy) if (e) (void)hipEventDestroy(e);
         if (h_weather) (void)hipHostFree(h_weather);
         if (h_zone_ab) (void)hipHostFree(h_zone_ab);
         for (int i = 0; i < kSideStreams; i++) {
@@ -404,13 +426,50 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     b->partial_ptr = b->d_partial.p;
     HIP_TRY(b->d_state.zeros(p.n_state));
     HIP_TRY(b->d_step.zeros(1));
-    HIP_TRY(b->d_flags.zeros(1));
+    HIP_TRY(b->d_flags.zeros(4));  // [0] kinds OR-ed, [2..3] first failing surface / zone (report_failure, kernels.hip)
+    HIP_TRY(hipMemset(b->d_flags.p + 2, 0xff, 2 * sizeof(int)));
+    b->h_orig_of = p.orig_of;
     HIP_TRY(b->d_nomass_iters.zeros(p.n_nm_counters));
     if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
 
     {
         const int rc = rebuild_unified(b);
         if (rc) return rc;
+    }
+    {   // compact transfers
+        b->h_in_slots.assign(p.slots.begin() + 4 * S, p.slots.end());
+        b->h_node_off.assign(d->node_offset, d->node_offset + S + 1);
+        if (S == 0) b->h_node_off.assign(1, 0);
+        std::vector<int64_t> coff(S);
+        std::vector<int32_t> oo(S);
+        for (int64_t dd = 0; dd < S; dd++) {
+            coff[dd] = d->node_offset[p.orig_of[dd]];
+            oo[dd] = (int32_t)p.orig_of[dd];
+        }
+        HIP_TRY(b->d_compact_off.upload(coff));
+        HIP_TRY(b->d_orig_of32.upload(oo));
+        const size_t n_out = (size_t)p.n_nodes + 4 * (size_t)S + (size_t)Z;
+        HIP_TRY(b->d_compact.alloc(std::max<size_t>(n_out, 1)));
+        // staging: two halves of up to 4 M doubles (32 MB) — a copy fills one while the pool empties the other; the
+        // inputs (4 S + Z) and the scalar outputs (4 S + Z) must fit one buffer as a whole
+        static const int stage_mb = getenv("HEAT_AMD_STAGE_MB") ? atoi(getenv("HEAT_AMD_STAGE_MB")) : 32;  // per half
+        const size_t kHalf = (size_t)std::max(stage_mb, 1) << 17;
+        b->pin_doubles = std::max<size_t>(2 * std::min<size_t>(kHalf, std::max<size_t>((size_t)p.n_nodes, 1)), 4 * (size_t)S + (size_t)Z + 1);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_pin), b->pin_doubles * sizeof(double)));
+        const size_t half = b->pin_doubles / 2;
+        b->out_chunks.clear();
+        for (int64_t s0 = 0; s0 < S;) {
+            int64_t s1 = s0 + 1;
+            while (s1 < S && (size_t)(d->node_offset[s1 + 1] - d->node_offset[s0]) <= half) s1++;
+            b->out_chunks.push_back({s0, s1});
+            s0 = s1;
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+        for (auto &e : b->ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        static const int n_env = getenv("HEAT_AMD_HOST_THREADS") ? atoi(getenv("HEAT_AMD_HOST_THREADS")) : 0;
+        const int hw = (int)std::thread::hardware_concurrency();
+        b->pool = new HostPool(n_env > 0 ? n_env : std::max(1, std::min(hw > 0 ? hw : 8, S > 20000 ? 16 : 1)));
+        if (getenv("HEAT_AMD_TRACE")) fprintf(stderr, "heat_amd: %d host threads, staging 2 x %zu MB, %zu node pieces\n", b->pool->size(), half * 8 >> 20, b->out_chunks.size());
     }
 
     // ---- argument bundles ----
@@ -841,35 +900,102 @@ static int transfer_in(heat_batch *b, const double *state, size_t n_state, bool 
 int heat_batch_upload_state(heat_batch *b, const double *state, size_t n_state) {
     return transfer_in(b, state, n_state, true);
 }
+// Only what other modules write between two marches (surface_trait.rs:81-125's irradiance slots, the zones'
+// dry-bulb slots): gathered on the host into pinned memory, one copy, converted on the device.
 int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state) {
-    return transfer_in(b, state, n_state, false);
-}
-
-int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
     if (!b || !state) return fail(HEAT_E_INVALID_ARG, "NULL argument");
     if ((int64_t)n_state != b->n_state) return fail(HEAT_E_SIZE, "n_state %zu, batch was created for %lld", n_state, (long long)b->n_state);
     int rc = select_device(b);
     if (rc) return rc;
-    for (int c = 0; c < kNumFast; c++)
-        launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
-                          b->d_first_slot.p, b->d_state.p, 1, b->stream);
-    launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p, b->d_state.p,
-                         1, b->stream);
-    launch_surf_scalars((int)b->n_surf, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_side_alpha.p, b->d_state.p, 1, 2,
-                        b->stream);
-    launch_zone_scalars((int)b->n_zones, b->d_zone_slot.p, b->d_zone_T.p, b->d_state.p, 1, b->stream);
+    HIP_TRY(hipStreamSynchronize(b->stream));  // (the staging buffer may still feed the previous call's copy)
+    const int64_t S = b->n_surf, Z = b->n_zones;
+    double *pin = b->h_pin;
+    const int64_t *slots = b->h_in_slots.data();
+    b->pool->run(4 * S, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) pin[i] = state[slots[i]];
+    });
+    for (int64_t z = 0; z < Z; z++) pin[4 * S + z] = state[b->h_zone_slot_h[z]];
+    if (4 * S + Z > 0)
+        HIP_TRY(hipMemcpyAsync(b->d_compact.p, pin, (size_t)(4 * S + Z) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    launch_inputs_compact((int)S, (int)Z, b->d_compact.p, b->d_side_alpha.p, b->d_side_dyn.p, b->d_zone_T.p, b->stream);
+    HIP_TRY(hipGetLastError());
+    return HEAT_OK;
+}
+
+int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
+    return heat_batch_download_outputs(b, state, n_state, HEAT_OUT_ALL);
+}
+
+// The outputs of this path into the caller's state: gathered on the device into a compact buffer in the caller's
+// surface order, copied through two pinned staging halves (the copy of one piece runs while the thread pool
+// scatters the piece before it), only the slots the path owns are written.
+int heat_batch_download_outputs(heat_batch *b, double *state, size_t n_state, int32_t what) {
+    if (!b || !state) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    if ((int64_t)n_state != b->n_state) return fail(HEAT_E_SIZE, "n_state %zu, batch was created for %lld", n_state, (long long)b->n_state);
+    int rc = select_device(b);
+    if (rc) return rc;
+    const int64_t S = b->n_surf, Z = b->n_zones, N = b->n_nodes;
+    const bool nodes = (what & HEAT_OUT_NODE_TEMPERATURES) != 0;
+    const bool scalars = (what & (HEAT_OUT_SURFACE_SCALARS | HEAT_OUT_ZONE_TEMPERATURES)) != 0;
+    if (nodes) {
+        for (int c = 0; c < kNumFast; c++)
+            launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
+                              b->d_compact_off.p, b->d_compact.p, 1, b->stream);
+        launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_compact_off.p, b->d_compact.p,
+                             1, b->stream);
+    }
+    if (scalars)
+        launch_outputs_compact((int)S, (int)Z, b->d_side_out.p, b->d_orig_of32.p, b->d_zone_T.p, b->d_compact.p + N, b->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->stream));
-    // Only the slots this path owns are written into the caller's array.
-    b->h_stage.resize(n_state);
-    HIP_TRY(hipMemcpy(b->h_stage.data(), b->d_state.p, n_state * sizeof(double), hipMemcpyDeviceToHost));
-    const double *src = b->h_stage.data();
-    for (int64_t s = 0; s < b->n_surf; s++) {
-        memcpy(state + b->h_first_slot[s], src + b->h_first_slot[s], (size_t)b->h_node_count[s] * sizeof(double));
-        for (int a = 0; a < 4; a++) state[b->h_out_slots[a][s]] = src[b->h_out_slots[a][s]];
+    const size_t half = b->pin_doubles / 2;
+    // the scalar part first (one piece), then the node pieces; piece i uses staging half i % 2
+    struct Piece { int64_t off, count, s0, s1; bool is_nodes; };
+    std::vector<Piece> pieces;
+    if (scalars) pieces.push_back({N, 4 * S + Z, 0, S, false});
+    if (nodes)
+        for (auto &ch : b->out_chunks)
+            pieces.push_back({b->h_node_off[ch.first], b->h_node_off[ch.second] - b->h_node_off[ch.first], ch.first, ch.second, true});
+    auto issue = [&](size_t i) -> hipError_t {
+        const Piece &p = pieces[i];
+        // (the scalar piece may be longer than a half: it is alone in the buffer then — the node pieces start after it)
+        double *dst = b->h_pin + (i % 2) * half;
+        hipError_t e = hipMemcpyAsync(dst, b->d_compact.p + p.off, (size_t)p.count * sizeof(double), hipMemcpyDeviceToHost, b->copy_stream);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(b->ev_copy[i % 2], b->copy_stream);
+    };
+    const bool big_scalars = scalars && (size_t)(4 * S + Z) > half;
+    for (size_t i = 0; i < pieces.size(); i++) {
+        if (i == 0) HIP_TRY(issue(0));
+        HIP_TRY(hipEventSynchronize(b->ev_copy[i % 2]));
+        // the next copy runs while this piece is scattered (not into a buffer the scalar piece spills over)
+        const bool overlap = i + 1 < pieces.size() && !(big_scalars && i == 0);
+        if (overlap) HIP_TRY(issue(i + 1));
+        const Piece &p = pieces[i];
+        const double *src = b->h_pin + (i % 2) * half;
+        if (p.is_nodes) {
+            const int64_t base = p.off;
+            b->pool->run(p.s1 - p.s0, [&](int64_t q0, int64_t q1) {
+                for (int64_t s = p.s0 + q0; s < p.s0 + q1; s++)
+                    memcpy(state + b->h_first_slot[s], src + (b->h_node_off[s] - base), (size_t)b->h_node_count[s] * sizeof(double));
+            });
+        } else {
+            if (what & HEAT_OUT_SURFACE_SCALARS)
+                b->pool->run(S, [&](int64_t s0, int64_t s1) {
+                    for (int64_t s = s0; s < s1; s++) {
+                        const double *v = src + 4 * s;  // hs_f, hs_b, flow_f, flow_b
+                        state[b->h_out_slots[0][s]] = v[0];
+                        state[b->h_out_slots[1][s]] = v[1];
+                        state[b->h_out_slots[2][s]] = v[2];
+                        state[b->h_out_slots[3][s]] = v[3];
+                    }
+                });
+            if (what & HEAT_OUT_ZONE_TEMPERATURES)
+                for (int64_t z = 0; z < Z; z++)
+                    if (b->h_owned[z]) state[b->h_zone_slot_h[z]] = src[4 * S + z];
+        }
+        if (!overlap && i + 1 < pieces.size()) HIP_TRY(issue(i + 1));
     }
-    for (int64_t z = 0; z < b->n_zones; z++)
-        if (b->h_owned[z]) state[b->h_zone_slot_h[z]] = src[b->h_zone_slot_h[z]];
     return HEAT_OK;
 }
 
@@ -1307,24 +1433,47 @@ int heat_batch_synchronize(heat_batch *b) {
     int rc = select_device(b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
-    int f = 0;
-    HIP_TRY(hipMemcpy(&f, b->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
-    if (f) {
-        HIP_TRY(hipMemset(b->d_flags.p, 0, sizeof f));
-        return flags_to_status(f);
+    int f[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(f, b->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    if (f[0]) {
+        unsigned long long where;
+        memcpy(&where, f + 2, sizeof where);
+        HIP_TRY(hipMemset(b->d_flags.p, 0, 2 * sizeof(int)));
+        HIP_TRY(hipMemset(b->d_flags.p + 2, 0xff, 2 * sizeof(int)));
+        // the first place (smallest number) and the kind that was seen there
+        const int kinds = (int)(where & 0xff);
+        const int64_t idx = (int64_t)(where >> 8);
+        const bool zone = (kinds & FLAG_NAN_ZONE) && !(kinds & (FLAG_NAN_HS | FLAG_NAN_NOMASS | FLAG_UNREACHABLE));
+        b->fail_kind = flags_to_status(kinds ? kinds : f[0]);
+        b->fail_index = zone ? idx : ((idx >= 0 && idx < (int64_t)b->h_orig_of.size()) ? b->h_orig_of[idx] : -1);
+        const int rc2 = flags_to_status(f[0]);
+        const std::string what = heat::last_error();
+        return fail(rc2, "%s; first seen at %s %lld", what.c_str(), zone ? "zone" : "surface", (long long)b->fail_index);
     }
+    return HEAT_OK;
+}
+
+int heat_batch_failed_surface(const heat_batch *b, int64_t *index, int32_t *kind) {
+    if (!b || !index || !kind) return fail(HEAT_E_INVALID_ARG, "NULL argument");
+    *index = b->fail_index;
+    *kind = b->fail_kind;
     return HEAT_OK;
 }
 
 int heat_batch_march(heat_batch *b, double *state, size_t n_state, const heat_weather *weather, int32_t n_sub,
                      const double *zone_a0, const double *zone_b0) {
+    return heat_batch_march_ex(b, state, n_state, weather, n_sub, zone_a0, zone_b0, HEAT_OUT_ALL);
+}
+
+int heat_batch_march_ex(heat_batch *b, double *state, size_t n_state, const heat_weather *weather, int32_t n_sub,
+                        const double *zone_a0, const double *zone_b0, int32_t what) {
     int rc = heat_batch_upload_inputs(b, state, n_state);
     if (rc) return rc;
     rc = heat_batch_march_resident(b, weather, n_sub, zone_a0, zone_b0);
     if (rc) return rc;
     rc = heat_batch_synchronize(b);
     if (rc) return rc;
-    return heat_batch_download_state(b, state, n_state);
+    return heat_batch_download_outputs(b, state, n_state, what);
 }
 
 int64_t heat_batch_nomass_iterations(heat_batch *b) {

@@ -64,6 +64,14 @@ __device__ __forceinline__ void put_zone_contrib(const SideArrays &sd, const Sid
     }
 }
 
+// A numerical failure (the reference panics there: surface.rs:704-707,850; model.rs:417-420): the kind goes into
+// the flag word, and the FIRST place it happened — smallest device surface (or zone) number — into the 64-bit word
+// behind it: number << 8 | kind bits. Rare by nature: no cost on the good path.
+__device__ __forceinline__ void report_failure(int *flags, int bad, unsigned int index) {
+    atomicOr(flags, bad);
+    atomicMin(reinterpret_cast<unsigned long long *>(flags + 2), ((unsigned long long)index << 8) | (unsigned int)(bad & 0xff));
+}
+
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
 
 // Neighbour exchange across the whole wavefront as DPP rotates (VALU speed; a ds_bpermute round trip through the
@@ -332,7 +340,7 @@ __device__ __forceinline__ unsigned int small_tile_march(int64_t node_base, int 
         put_zone_contrib(sd, cf, of.hs, T[0]);
         put_zone_contrib(sd, cb, ob.hs, Tl);
     }
-    if (bad) atomicOr(flags, bad);
+    if (bad) report_failure(flags, bad, (unsigned int)d);
     return iters;
 }
 
@@ -468,7 +476,7 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
         sd.out[S + d] = ob;
         if (fa.small_iters) fa.small_iters[(int64_t)tile_index * kWave + lane] += iters;
     }
-    if (bad_all) atomicOr(flags, bad_all);  // (lane 0 of a zone-owning wave may carry a zone flag while inactive)
+    if (bad_all) report_failure(flags, bad_all, (unsigned int)d);  // (lane 0 of a zone-owning wave may carry a zone flag while inactive)
 }
 #pragma clang fp contract(fast)
 
@@ -894,7 +902,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         o.flow = o2_flow;
         sd.out[S + d] = o;
     }
-    if (active && bad_all) atomicOr(flags, bad_all);
+    if (active && bad_all) report_failure(flags, bad_all, (unsigned int)d);
     if constexpr (NM) {
         // passes of the no-mass loop, summed per tile (one owner per slot: no atomics on a shared word)
         unsigned int tot = nm_passes;
@@ -1269,7 +1277,7 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
         put_zone_contrib(sd, cf, fh, T0n);
         put_zone_contrib(sd, cb, bh, Tnn);
     }
-    if (bad) atomicOr(flags, bad);
+    if (bad) report_failure(flags, bad, (unsigned int)d);
     if (iters) nomass_iters[(int64_t)wave * kWave + lane] += iters;  // one slot per lane of the tile
 #undef SC
 #undef TT
@@ -1341,7 +1349,7 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
     const double c = zone_mcp(zv, tc);  // model.rs:549-552
     double ft = tc;
     if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);  // model.rs:662-666
-    if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);                      // model.rs:417-420
+    if (ft != ft) report_failure(flags, FLAG_NAN_ZONE, (unsigned int)z);  // model.rs:417-420
     zone_T[z] = ft;
 }
 
@@ -1363,7 +1371,7 @@ k_zone_update(const double *__restrict__ gathered, int n_blocks, const double *_
     const double c = zone_mcp(zone_vol[z], tc);
     double ft = tc;
     if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);
-    if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);
+    if (ft != ft) report_failure(flags, FLAG_NAN_ZONE, (unsigned int)z);
     zone_T[z] = ft;
 }
 
@@ -1385,7 +1393,7 @@ k_zone_update_shared(const double *__restrict__ gathered, int n_blocks, const in
     const double c = zone_mcp(zone_vol[z], tc);
     double ft = tc;
     if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * dt / c);
-    if (ft != ft) atomicOr(flags, FLAG_NAN_ZONE);
+    if (ft != ft) report_failure(flags, FLAG_NAN_ZONE, (unsigned int)z);
     zone_T[z] = ft;
 }
 
@@ -1494,6 +1502,45 @@ k_zone_scalars(int n_zones, const int64_t *__restrict__ zone_slot, double *__res
     if (z >= n_zones) return;
     if (to_state) state[zone_slot[z]] = zone_T[z];
     else zone_T[z] = state[zone_slot[z]];
+}
+
+// heat_batch_march on a caller-owned state, compact transfers: what other modules write between two
+// marches arrives as [solar_f[S] | solar_b[S] | ir_f[S] | ir_b[S] | zone T[Z]] in device surface order (gathered on
+// the host, one pinned copy) — the clamps and conversions of k_surf_scalars, without the state mirror.
+__global__ void __launch_bounds__(256)
+k_inputs_compact(int n_surf, int n_zones, const double *__restrict__ in, const double *__restrict__ side_alpha,
+                 SideDyn *__restrict__ dyn, double *__restrict__ zone_T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = n_surf;
+    if (i < S) {
+        double sf = in[i];
+        if (sf != sf || sf < 0.0) sf = 0.0;  // surface.rs:916-923
+        double sb = in[S + i];
+        if (sb != sb) sb = 0.0;
+        SideDyn f, b;
+        f.solar = sf * side_alpha[i];
+        f.rad_t = ir_to_rad_temperature(in[2 * (int64_t)S + i]);
+        b.solar = sb * side_alpha[S + i];
+        b.rad_t = ir_to_rad_temperature(in[3 * (int64_t)S + i]);
+        dyn[i] = f;
+        dyn[S + i] = b;
+    }
+    if (i < n_zones) zone_T[i] = in[4 * (int64_t)S + i];
+}
+
+// The outputs this path owns besides the node temperatures, compact: [hs_f, hs_b, flow_f, flow_b] per surface in
+// the CALLER's surface order, then the zone temperatures.
+__global__ void __launch_bounds__(256)
+k_outputs_compact(int n_surf, int n_zones, const SideOut *__restrict__ out, const int32_t *__restrict__ orig_of,
+                  const double *__restrict__ zone_T, double *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_surf) {
+        const SideOut f = out[i], b = out[n_surf + i];
+        double2 *p = reinterpret_cast<double2 *>(dst + 4 * (int64_t)orig_of[i]);
+        p[0] = make_double2(f.hs, b.hs);
+        p[1] = make_double2(f.flow, b.flow);
+    }
+    if (i < n_zones) dst[4 * (int64_t)n_surf + i] = zone_T[i];
 }
 
 __global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
@@ -1699,6 +1746,20 @@ void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, 
     if (n_zones <= 0) return;
     hipLaunchKernelGGL(k_zone_scalars, dim3((n_zones + 255) / 256), dim3(256), 0, st, n_zones, zone_slot, zone_T,
                        state, to_state);
+}
+
+void launch_inputs_compact(int n_surf, int n_zones, const double *in, const double *side_alpha, SideDyn *dyn, double *zone_T,
+                           hipStream_t st) {
+    const int n = std::max(n_surf, n_zones);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_inputs_compact, dim3((n + 255) / 256), dim3(256), 0, st, n_surf, n_zones, in, side_alpha, dyn, zone_T);
+}
+
+void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const int32_t *orig_of, const double *zone_T,
+                            double *dst, hipStream_t st) {
+    const int n = std::max(n_surf, n_zones);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_outputs_compact, dim3((n + 255) / 256), dim3(256), 0, st, n_surf, n_zones, out, orig_of, zone_T, dst);
 }
 
 void launch_set_step(int *step_ptr, int v, hipStream_t st) {

@@ -171,12 +171,34 @@ int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state)
  */
 int heat_batch_march(heat_batch *b, double *state, size_t n_state, const heat_weather *weather,
                      int32_t n_sub, const double *zone_a0, const double *zone_b0);
+/* Data at this boundary: the call uploads only the slots other modules write between two marches
+ * — the 4 S irradiance slots and the zones' dry-bulb slots, gathered on the host into pinned memory, one 32 MB copy
+ * per million surfaces — and downloads only the outputs of this module, through two pinned staging halves with the
+ * host scatter on a thread pool (HEAT_AMD_HOST_THREADS, default min(16, cores)) overlapping the copies.
+ * heat_batch_march_ex chooses which outputs come back every call: a caller that reads the node temperatures only
+ * now and then (they are 8 n of every surface's 8 n + 32 output bytes) leaves HEAT_OUT_NODE_TEMPERATURES out and
+ * fetches them with heat_batch_download_outputs when needed; the device-resident state is always complete. */
+enum heat_outputs {
+    HEAT_OUT_NODE_TEMPERATURES = 1, /* SurfaceTrait::set_node_temperatures, surface_trait.rs:107-125 */
+    HEAT_OUT_SURFACE_SCALARS = 2,   /* hs front / back, convective heat flow front / back (model.rs:154-169) */
+    HEAT_OUT_ZONE_TEMPERATURES = 4, /* dry-bulb temperature of the zones this batch owns (model.rs:410-423) */
+    HEAT_OUT_ALL = 7
+};
+int heat_batch_march_ex(heat_batch *b, double *state, size_t n_state, const heat_weather *weather, int32_t n_sub,
+                        const double *zone_a0, const double *zone_b0, int32_t what);
+int heat_batch_download_outputs(heat_batch *b, double *state, size_t n_state, int32_t what);
 
 /* Same, but on the device-resident state only (no host traffic; asynchronous on the batch's
  * stream until heat_batch_synchronize / a download). */
 int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_t n_sub,
                               const double *zone_a0, const double *zone_b0);
 int heat_batch_synchronize(heat_batch *b); /* waits, then reports device-side numerical flags */
+/* Where the numerical failure heat_batch_synchronize / heat_batch_march last reported was seen FIRST (the reference's
+ * panics name the offending values, surface.rs:704-707; model.rs:417-420): *index = the surface's number in the
+ * descriptor — or the zone's, when *kind == HEAT_N_NAN_ZONE found by the zone balance itself (the cluster-resident
+ * march reports a surface of the zone's cluster instead) — and *kind = the HEAT_N_* code seen there. -1 / 0 when no
+ * failure has been reported yet. Host-side bookkeeping: no device access. */
+int heat_batch_failed_surface(const heat_batch *b, int64_t *index, int32_t *kind);
 
 /* Split-phase sub-timestep, for the sharded (multi-GPU) case. All asynchronous on the stream.
  * step_surfaces ≙ iterate_surfaces over this rank's surfaces + this rank's partial (a,b) sums.

@@ -190,6 +190,35 @@ def test_error_codes(oracle):
         assert e.value.code > 0  # numerical failure, like the reference's panic
 
 
+@pytest.mark.parametrize("mode", ["planned", "streamed", "general"])
+def test_numerical_failure_names_the_surface(mode):
+    """The reference's panic on a NaN convection coefficient names the values (surface.rs:704-707); the library
+    reports the first offending surface by its number in the caller's descriptor — whichever kernel it ran in."""
+    md, st = mdl.clustered_massive(700, Z=28, dt=45.0, seed=3)
+    bad = [411, 97, 605]                                  # 97 is the first in the caller's order
+    n = np.diff(md["node_offset"])
+    for s_ in bad:
+        st[md["first_node_slot"][s_]] = np.nan            # NaN front temperature -> NaN hs on that surface
+    kw = dict(planned={}, streamed=dict(no_fusion=True), general=dict(force_general=True))[mode]
+    with HeatBatch(md, **kw) as b:
+        assert b.failed_surface() == (-1, 0)
+        b.upload_state(st)
+        b.march_resident(mdl.weather_series(1, 45.0))
+        with pytest.raises(HeatError) as e:
+            b.synchronize()
+        assert e.value.code > 0
+        idx, kind = b.failed_surface()
+        assert idx in bad and kind == e.value.code, (idx, kind, str(e.value))
+        assert "surface %d" % idx in str(e.value)
+        if mode != "planned":
+            # one sub-timestep, streamed: only the three surfaces themselves are bad, and the smallest DEVICE number
+            # wins — every reported index must be one of them; after the report the record is cleared on the device
+            assert idx in bad
+        b.upload_state(mdl.initial_state(md))
+        b.march_resident(mdl.weather_series(2, 45.0))
+        b.synchronize()                                   # healthy again
+
+
 @pytest.mark.parametrize("case", ["massive_no_ir_no_solar", "mixed_no_ir_no_solar", "nomass_no_ir_no_solar", "massive_full",
                                   "mixed_full", "nomass_full", "massive_no_ir_yes_solar", "mixed_yes_ir_no_solar"])
 def test_config1_energyplus_series_through_the_abi(oracle, case):

@@ -4,6 +4,7 @@
 # writes OUT_DIR/{insts,cycles,fetch,write}/.../*counter_collection.csv
 set -e
 out=$1; shift; shift
+mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/insts -- "$@" > $out/insts.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $out/cycles -- "$@" > $out/cycles.log 2>&1
