@@ -30,9 +30,11 @@ def read_csv(d):
 
 
 def main():
-    # the twelve wall cases the reference registers (validate_wall_heat_transfer.rs:817-994)
+    # the fourteen wall series the reference registers: twelve constructions x radiation cases
+    # (validate_wall_heat_transfer.rs:817-994) and the tilted / horizontal walls (:792-815, geometry in
+    # tests/{tilted,horizontal}/back.spl)
     for d in [c + "_" + r for c in ("massive", "mixed", "nomass")
-              for r in ("full", "no_ir_no_solar", "no_ir_yes_solar", "yes_ir_no_solar")]:
+              for r in ("full", "no_ir_no_solar", "no_ir_yes_solar", "yes_ir_no_solar")] + ["tilted", "horizontal"]:
         a = read_csv(d)[:7000]
         np.savez_compressed(os.path.join(HERE, "wall_%s.npz" % d), wind_speed=a[:, 0], wind_dir_deg=a[:, 1],
                             solar=a[:, 2], t_out=a[:, 7], ir_gain=a[:, 10], zone_t=a[:, 11])

@@ -23,8 +23,9 @@ from heat_amd import modeldict as mdl
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def single_zone_model(oracle, layers, emissivity, solar_abs, n_per_hour=20):
-    """ThermalModel::new for get_single_zone_test_building (model.rs:215-354)."""
+def single_zone_model(oracle, layers, emissivity, solar_abs, n_per_hour=20, normal=(0., -1., 0.), height=1.5):
+    """ThermalModel::new for get_single_zone_test_building (model.rs:215-354); `normal` / `height`: the wall's
+    normal and centroid height (vertical 20 m x 3 m by default; tests/{tilted,horizontal}/back.spl otherwise)."""
     main_dt = 3600. / n_per_hour
     lay = []
     for L in layers:
@@ -34,13 +35,13 @@ def single_zone_model(oracle, layers, emissivity, solar_abs, n_per_hour=20):
         L["front_solar_abs"] = solar_abs
         L["back_solar_abs"] = solar_abs
         lay.append(L)
-    d = oracle.discretize(lay, main_dt, 0.04, 60., 1., math.acos(0.0))  # max_dx, min_dt: model.rs:236-237
+    d = oracle.discretize(lay, main_dt, 0.04, 60., 1., math.acos(normal[2]))  # max_dx, min_dt: model.rs:236-237
     sub = d["tstep_subdivision"]
     dt = 3600. / (n_per_hour * sub) / 2.   # SAFETY = 2, model.rs:326-331
     n_sub = sub * 2
     md, state = surfaces_model(d, dt, mdl.OUTDOOR, mdl.SPACE, n_zones=1, zone_volume=[600.],
                                front_emis=lay[0]["front_thermal_abs"], back_emis=0.0,  # back_emissivity = 0: validate_wall_heat_transfer.rs:630
-                               area=60., perimeter=46., cos_tilt=0.0, normal=(0., -1., 0.), height=1.5)
+                               area=60., perimeter=46., cos_tilt=normal[2], normal=normal, height=height)
     return md, state, d, n_sub
 
 
@@ -75,6 +76,14 @@ _RADIATION = {"full": (0.9, 0.7), "no_ir_no_solar": (0.0, 0.0), "no_ir_yes_solar
 # dir: (layers, emissivity, solar absorptance) — the twelve cases of validate_wall_heat_transfer.rs:817-994
 CASES = {"%s_%s" % (c, r): (_CONSTRUCTIONS[c], _RADIATION[r][0], _RADIATION[r][1])
          for c in _CONSTRUCTIONS for r in _RADIATION}
+# the two non-vertical walls (validate_wall_heat_transfer.rs:792-815): 20 cm concrete, emissivity 0.9 and solar
+# absorptance 0.7 from tests/{tilted,horizontal}/back.spl; the geometry from the files' vertices — tilted: a
+# 20 m x 3 m rectangle rising 45 degrees, normal (0, -1, 1)/sqrt 2, centroid 1.06 m up; horizontal: 20 m x 3 m facing
+# up at z = 14.9 m. Area 60 m2 (march_simple_model's argument), perimeter 46 m.
+CASES["tilted"] = (_CONSTRUCTIONS["massive"], 0.9, 0.7)
+CASES["horizontal"] = (_CONSTRUCTIONS["massive"], 0.9, 0.7)
+GEOMETRY = {"tilted": dict(normal=(0., -1. / math.sqrt(2.), 1. / math.sqrt(2.)), height=2.12132034357 / 2.),
+            "horizontal": dict(normal=(0., 0., 1.), height=14.9)}
 
 
 def test_config1_discretization_is_as_surveyed(oracle):
@@ -93,17 +102,19 @@ def test_config1_discretization_is_as_surveyed(oracle):
 
 
 # RMSE of the zone temperature against EnergyPlus over rows 5001..7000, measured with this oracle (°C):
+#   tilted 0.163, horizontal 0.196
 #   massive: full 0.077, no_ir_no_solar 0.033, no_ir_yes_solar 0.066, yes_ir_no_solar 0.052
 #   mixed:   full 0.059, no_ir_no_solar 0.028, no_ir_yes_solar 0.255, yes_ir_no_solar 0.102
 #   nomass:  full 0.265, no_ir_no_solar 0.133, no_ir_yes_solar 0.230, yes_ir_no_solar 0.190
 @pytest.mark.parametrize("case,max_rmse", [
     ("massive_full", 0.15), ("massive_no_ir_no_solar", 0.1), ("massive_no_ir_yes_solar", 0.15), ("massive_yes_ir_no_solar", 0.1),
     ("mixed_full", 0.12), ("mixed_no_ir_no_solar", 0.1), ("mixed_no_ir_yes_solar", 0.4), ("mixed_yes_ir_no_solar", 0.2),
-    ("nomass_full", 0.4), ("nomass_no_ir_no_solar", 0.25), ("nomass_no_ir_yes_solar", 0.4), ("nomass_yes_ir_no_solar", 0.3)])
+    ("nomass_full", 0.4), ("nomass_no_ir_no_solar", 0.25), ("nomass_no_ir_yes_solar", 0.4), ("nomass_yes_ir_no_solar", 0.3),
+    ("tilted", 0.35), ("horizontal", 0.4)])
 def test_zone_temperature_tracks_energyplus(oracle, case, max_rmse):
     layers, emis, sol = CASES[case]
     fx = np.load(os.path.join(GOLD, "wall_%s.npz" % case))
-    md, state, d, n_sub = single_zone_model(oracle, layers, emis, sol)
+    md, state, d, n_sub = single_zone_model(oracle, layers, emis, sol, **GEOMETRY.get(case, {}))
     found = march_series(oracle, md, state, n_sub, fx, emis)
     exp = fx["zone_t"]
     sel = slice(5001, None)  # skip warm-up, validate_wall_heat_transfer.rs:669-673

@@ -110,6 +110,39 @@ def test_config5_glazing_and_cavities(oracle):
     assert_state_close(md, ref, got)
 
 
+def test_config2_and_config5_at_baseline_size(oracle):
+    """BASELINE.json's configs 2 and 5 at their full sizes against the oracle (it runs them in seconds on the host
+    cores): 10 000 identical 3-layer walls x 20 nodes x 200 sub-timesteps; 100 000 double glazings + 100 000
+    Trombe-like walls x 25 sub-timesteps. The planner's choice and the streamed kernels both."""
+    md, st = mdl.uniform_massive(10_000, 20, Z=100, dt=90.0, identical=True, vertical=True)
+    w = mdl.weather_series(200, 90.0)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, threads=16)
+    assert rc == 0
+    for kw in (dict(), dict(no_fusion=True)):
+        got = st.copy()
+        with HeatBatch(md, use_graph=True, **kw) as b:
+            b.upload_state(got)
+            for i in range(0, 200, 20):                 # ten march calls of 20 sub-timesteps
+                b.march_resident(w[i:i + 20])
+            b.synchronize()
+            b.download_state(got)
+        assert_state_close(md, ref, got)
+    md, st = mdl.glazing_cavity(200_000, Z=2000, dt=45.0)
+    w = mdl.weather_series(25, 45.0)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, threads=16)
+    assert rc == 0
+    got = st.copy()
+    with HeatBatch(md) as b:
+        b.upload_state(got)
+        b.march(got, w)
+        counts = b.class_counts()
+        assert b.nomass_iterations() == iters
+    assert counts[3] > 90_000 and sum(counts[:3]) > 90_000 and counts[4] == 0
+    assert_state_close(md, ref, got)
+
+
 def test_reference_unit_test_walls_through_the_abi(oracle):
     # test_march_massive_1 / test_march_nomass (surface.rs:1087-1443) with the debug hs overrides
     lay = [dict(thickness=20. / 1000., **BRICKWORK)]
@@ -188,6 +221,29 @@ def test_error_codes(oracle):
         with pytest.raises(HeatError) as e:
             b.march(st, np.array([[10., 0., 1.]]))
         assert e.value.code > 0  # numerical failure, like the reference's panic
+
+
+def test_all_fourteen_energyplus_series_through_the_abi_full_length(oracle):
+    """every wall series the reference registers (validate_wall_heat_transfer.rs:792-994 — twelve
+    construction x radiation cases, the tilted and the horizontal wall) over its full 7 000 rows (5 000 warm-up +
+    2 000 compared) through heat_batch_march on a caller-owned state: the same zone temperatures as the oracle's
+    harness at 1e-9 and the same RMSE against EnergyPlus. tools/validation_table.py writes the table."""
+    import os
+    from test_energyplus_series import CASES, GEOMETRY, GOLD, march_series, single_zone_model
+    for case in sorted(CASES):
+        layers, emis, sol = CASES[case]
+        fx = dict(np.load(os.path.join(GOLD, "wall_%s.npz" % case)))
+        md, st, d, n_sub = single_zone_model(oracle, layers, emis, sol, **GEOMETRY.get(case, {}))
+        ref = march_series(oracle, md, st.copy(), n_sub, fx, emis)
+        got_state = st.copy()
+        with HeatBatch(md) as b:
+            b.upload_state(got_state)
+            got = march_series(oracle, md, got_state, n_sub, fx, emis, march=lambda s, w: b.march(s, w))
+        assert np.allclose(got, ref, rtol=RTOL, atol=ATOL), case
+        sel = slice(5001, None)
+        rm_ref = float(np.sqrt(np.mean((ref[sel] - fx["zone_t"][sel]) ** 2)))
+        rm_got = float(np.sqrt(np.mean((got[sel] - fx["zone_t"][sel]) ** 2)))
+        assert abs(rm_ref - rm_got) < 1e-8 and rm_got < 0.5, (case, rm_ref, rm_got)
 
 
 @pytest.mark.parametrize("mode", ["planned", "streamed", "general"])
