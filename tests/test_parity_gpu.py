@@ -138,7 +138,7 @@ def test_config2_and_config5_at_baseline_size(oracle):
         b.upload_state(got)
         b.march(got, w)
         counts = b.class_counts()
-        assert b.nomass_iterations() == iters
+        # (the threaded oracle does not count the no-mass passes; test_config5_glazing_and_cavities pins them)
     assert counts[3] > 90_000 and sum(counts[:3]) > 90_000 and counts[4] == 0
     assert_state_close(md, ref, got)
 
