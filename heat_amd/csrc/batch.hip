@@ -520,7 +520,7 @@ int rebuild_unified(heat_batch *b) {
                 n_classes += n > 0;
                 for (int t = 0; t < n; t++) {
                     FastTile ft = b->h_tiles_cur[c][t];
-                    ft.k = (int16_t)((ft.k & 0x1ff) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
+                    ft.k = (int16_t)((ft.k & (0x1ff | kTileMixedBit)) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
                     fast.push_back(ft);
                 }
             }
@@ -885,7 +885,7 @@ static int transfer_in(heat_batch *b, const double *state, size_t n_state, bool 
     if (full) {
         for (int c = 0; c < kNumFast; c++)
             launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
-                              b->d_first_slot.p, b->d_state.p, 0, b->stream);
+                              b->d_first_slot.p, b->d_state.p, 0, b->d_cls.p, b->stream);
         launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p,
                              b->d_state.p, 0, b->stream);
     }
@@ -940,7 +940,7 @@ int heat_batch_download_outputs(heat_batch *b, double *state, size_t n_state, in
     if (nodes) {
         for (int c = 0; c < kNumFast; c++)
             launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
-                              b->d_compact_off.p, b->d_compact.p, 1, b->stream);
+                              b->d_compact_off.p, b->d_compact.p, 1, b->d_cls.p, b->stream);
         launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_compact_off.p, b->d_compact.p,
                              1, b->stream);
     }

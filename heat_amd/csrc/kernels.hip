@@ -497,13 +497,22 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     double2 *const s_hT = fl.hT;
     double *const s_zT = fl.zT;
     (void)s_hT; (void)s_zT; (void)s_V; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
-    const int k = tile.k & 0xff;
+    const bool mixed = PAL && (tile.k & kTileMixedBit) != 0;  // (wave-uniform) surfaces of different lane counts
+    const int k = tile.k & 0xff;                              // lanes per surface; mixed: lanes of the tile
     const bool full = (tile.k & 0x100) != 0;
     const int G = tile.G;
-    const int Lk = (kWave / k) * k;
+    const int Lk = mixed ? k : (kWave / k) * k;
     int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
-    const int seg = lane - g * k;
+    int seg = lane - g * k;
+    bool is_last = (seg == k - 1);
     const bool in_layout = lane < Lk;
+    if (mixed) {
+        // the lane's surface and segment from the tile's lane table (behind its class bytes, layout.hpp)
+        const unsigned int e = reinterpret_cast<const unsigned short *>(na.cls + tile.node_base + (int64_t)M * Lk)[in_layout ? lane : 0];
+        g = (int)(e & 63u);
+        seg = (int)((e >> 6) & 63u);
+        is_last = (e & (unsigned int)kLaneLastBit) != 0;
+    }
     const bool active = in_layout && (g < G);
     if (!active) g = 0;
     const int d = tile.surf_base + g;
@@ -513,20 +522,25 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     // lane loads the back side (only the last lane's is used). k == 1: both sides, see below. ----
     const int S = sd.S;
     const bool is_first = (seg == 0);
-    const bool is_last = (seg == k - 1);
+    // A surface of ONE lane owns both its sides on it (front as every first lane does, then the back). The
+    // cluster-resident march carries that path for 8 nodes per lane without gas cavities only (elsewhere the second
+    // side's registers cost a wavefront per SIMD or spill: those workgroups hold surfaces of two lanes or more — the
+    // host sees to it).
+    constexpr bool kSingleLane = !FUSED || (M == 8 && !CAV);
+    const bool single = kSingleLane && is_first && is_last;
     const bool my_back = !is_first;
     const int sidx = (my_back ? S : 0) + d;
     const SideConst c_load = sd.sc[sidx];
     const SideDyn dy_load = sd.dyn[sidx];
     const int kind_n_mine = c_load.kind_n;
-    // (FUSED workgroups hold surfaces of two or more lanes only — the host sees to it — so the "this lane owns
-    // both sides" path of single-lane surfaces is not compiled into them.)
-    int my_lz = 0;
+    int my_lz = 0, b_lz = 0;
     double my_area = 0.0;
     if constexpr (FUSED) {
         my_lz = fa.side_lzone[sidx];
         my_area = fa.side_area[sidx];
+        if constexpr (kSingleLane) b_lz = single ? fa.side_lzone[S + d] : 0;
     }
+    (void)b_lz;
 
     // ---- node data: T, V = dt/C, U (coalesced 16-byte loads) ----
     double T[M], V[M], U[M];
@@ -589,9 +603,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     }
     if constexpr (FUSED) fused_block_init(blk, fa, fl, blk_waves * kWave);  // the block's zone data -> LDS
 
-    const int first_lane = g * k;
+    const int first_lane = lane - seg;
     const int nn = kind_n_mine >> 16;
-    const int jl = full ? (M - 1) : (nn - 1 - (k - 1) * M);  // local index of the last node inside the last lane
+    // local index of the last node inside the last lane (the last lane's segment number is its surface's k - 1)
+    const int jl = full ? (M - 1) : (nn - 1 - (mixed ? seg : k - 1) * M);
 
     auto pick_last = [&](const double (&x)[M]) {
         double r = x[M - 1];
@@ -604,13 +619,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
 
     // does any back side of this tile face an ambient temperature? (wave-uniform)
     const bool wave_quirk = __any((is_last && (kind_n_mine & 3) == KIND_AMBIENT && my_back) ||
-                                  (k == 1 && (sd.sc[S + d].kind_n & 3) == KIND_AMBIENT));
+                                  (single && (sd.sc[S + d].kind_n & 3) == KIND_AMBIENT));
     int4 cavref = make_int4(-1, -1, -1, -1);
     if constexpr (CAV) cavref = reinterpret_cast<const int4 *>(na.cavref)[d];
     SideConst cb2 = c_load;
     SideDyn db2 = dy_load;
-    if constexpr (!FUSED) {
-        if (k == 1) {  // single-lane surfaces: this lane is also the last one
+    if constexpr (kSingleLane) {
+        if (single) {  // this lane is also the last one of its surface
             cb2 = sd.sc[S + d];
             db2 = sd.dyn[S + d];
         }
@@ -785,10 +800,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     }
     double b_air = 0.0, b_forced = 0.0, b_cos = 0.0, b_neg = 0.0;
     bool b_useF = false;
-    if constexpr (!FUSED) {
-        if (k == 1) {  // single-lane surfaces: this lane is also the last one
+    if constexpr (kSingleLane) {
+        if (single) {  // this lane is also the last one of its surface
             double b_rad;
-            prepare(cb2, db2, true, S + d, 0, b_air, b_rad, b_forced, b_useF);
+            prepare(cb2, db2, true, S + d, b_lz, b_air, b_rad, b_forced, b_useF);
             b_cos = cb2.cos_eff;
             b_neg = cb2.alpha;
             add_face(cb2, db2, true, b_air, b_rad, b_forced, S + d, b_useF, hB, qB);
@@ -869,11 +884,16 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                 s_hT[(my_back ? kLanes : 0) + wib * kWave + lane] = make_double2(hs * my_area, face_t);
         }
     }
-    if (!FUSED && k == 1) {
+    if (single) {
         const double hs = conv(b_air, b_forced, b_cos, b_neg, S + d, b_useF ? T0n : Tnn);
         o2_hs = hs;
         o2_flow = (Tln - b_air) * hs;
-        if (active) put_zone_contrib(sd, cb2, hs, Tln);
+        if constexpr (!FUSED) {
+            if (active) put_zone_contrib(sd, cb2, hs, Tln);
+        } else {
+            if (active && (cb2.kind_n & 3) == KIND_SPACE)
+                s_hT[kLanes + wib * kWave + lane] = make_double2(hs * my_area, Tln);
+        }
     } else if (!(is_first || is_last)) {
         bad = 0;
     }
@@ -896,7 +916,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         o.flow = o_flow;
         sd.out[sidx] = o;
     }
-    if (!FUSED && k == 1 && active) {
+    if (single && active) {
         SideOut o;
         o.hs = o2_hs;
         o.flow = o2_flow;
@@ -1039,7 +1059,7 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
         FastTile tile = tiles[w];
         const int kind = (tile.k >> kTileKindShift) & 3;
         const bool nm = (tile.k & kTileNmBit) != 0;
-        tile.k = (int16_t)(tile.k & 0x1ff);
+        tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit));
         switch (kind) {
         case 2:
             fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather,
@@ -1403,16 +1423,22 @@ template <int M>
 __global__ void __launch_bounds__(256)
 k_nodes_fast(const FastTile *__restrict__ tiles, int n_tiles, double *__restrict__ Tbuf,
              const int32_t *__restrict__ meta, const int64_t *__restrict__ first_slot,
-             double *__restrict__ state, int to_state) {
+             double *__restrict__ state, int to_state, const uint8_t *__restrict__ cls) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave >= n_tiles) return;
     const FastTile tile = tiles[wave];
+    const bool mixed = (tile.k & kTileMixedBit) != 0;
     const int k = tile.k & 0xff;
-    const int Lk = (kWave / k) * k;
-    const int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
-    const int seg = lane - g * k;
+    const int Lk = mixed ? k : (kWave / k) * k;
+    int g = (int)(((float)lane + 0.5f) * (1.0f / (float)k));
+    int seg = lane - g * k;
     if (lane >= Lk) return;
+    if (mixed) {
+        const unsigned int e = reinterpret_cast<const unsigned short *>(cls + tile.node_base + (int64_t)M * Lk)[lane];
+        g = (int)(e & 63u);
+        seg = (int)((e >> 6) & 63u);
+    }
     const bool active = g < tile.G;
     const int d = tile.surf_base + (active ? g : 0);
     const int nn = active ? (meta[d] & 0xffff) : 0;
@@ -1717,13 +1743,13 @@ void launch_zone_update(const double *gathered, int n_blocks, const double *a0, 
 }
 
 void launch_nodes_fast(int M, const FastTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
-                       const int64_t *first_slot, double *state, int to_state, hipStream_t st) {
+                       const int64_t *first_slot, double *state, int to_state, const uint8_t *cls, hipStream_t st) {
     if (n_tiles <= 0) return;
     const dim3 grid(blocks_for_waves(n_tiles)), block(256);
     switch (M) {
-    case 4: hipLaunchKernelGGL(k_nodes_fast<4>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state); break;
-    case 8: hipLaunchKernelGGL(k_nodes_fast<8>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state); break;
-    default: hipLaunchKernelGGL(k_nodes_fast<16>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state); break;
+    case 4: hipLaunchKernelGGL(k_nodes_fast<4>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state, cls); break;
+    case 8: hipLaunchKernelGGL(k_nodes_fast<8>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state, cls); break;
+    default: hipLaunchKernelGGL(k_nodes_fast<16>, grid, block, 0, st, tiles, n_tiles, Tbuf, meta, first_slot, state, to_state, cls); break;
     }
 }
 

@@ -44,7 +44,7 @@ void launch_zone_update(const double *gathered, int n_blocks, const double *a0, 
                         const double *zone_vol, double *zone_T, int n_zones, double dt, int *step_ptr,
                         int *flags, hipStream_t st);
 void launch_nodes_fast(int M, const FastTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
-                       const int64_t *first_slot, double *state, int to_state, hipStream_t st);
+                       const int64_t *first_slot, double *state, int to_state, const uint8_t *cls, hipStream_t st);
 void launch_nodes_general(const GeneralTile *tiles, int n_tiles, double *Tbuf, const int32_t *meta,
                           const int64_t *first_slot, double *state, int to_state, hipStream_t st);
 void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut *out, const double *side_alpha,

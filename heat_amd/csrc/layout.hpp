@@ -33,9 +33,18 @@ enum : int { FLAG_NAN_HS = 1, FLAG_NAN_NOMASS = 2, FLAG_NAN_ZONE = 4, FLAG_UNREA
 struct FastTile {
     int64_t node_base;  // in doubles, into the unified node buffers
     int32_t surf_base;  // first device surface of the tile
-    int16_t k;          // bits 0-7: lanes per surface; bit 8: every surface of the tile has n == k * M
+    int16_t k;          // bits 0-7: lanes per surface; bit 8: every surface of the tile has n == k * M;
+                        // bits 9-11: kind tags of the unified streamed list (kernels.hpp);
+                        // bit 12 (kTileMixedBit): MIXED tile — bits 0-7 are the lanes the tile uses (Lk), its surfaces
+                        // have lane counts of their own and follow each other in the lanes; lane l's surface and
+                        // segment come from a table of 64 16-bit entries behind the tile's class bytes, at
+                        // cls + node_base + M * Lk:  bits 0-5 surface of the tile, 6-11 segment, 12 last segment.
+                        // (The workgroups of the cluster-resident march pack their clusters' walls this way.)
     int16_t G;          // surfaces in this tile
 };
+constexpr int kTileMixedBit = 1 << 12;
+constexpr int kLaneLastBit = 1 << 12;
+constexpr int kLaneTableSlots = 128;  // node slots a mixed tile takes behind its M * Lk for the table (128 bytes used)
 
 struct GeneralTile {
     int64_t node_base;  // in doubles

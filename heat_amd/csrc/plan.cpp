@@ -36,12 +36,16 @@ struct Placed {
     int blk;     // cluster-resident march: workgroup number, -1 = streamed
 };
 
-// Tiles a set of fast-path surfaces needs: surfaces of equal k share a tile, floor(64 / k) per tile.
-int tiles_needed(const int (&cnt)[kWave + 1]) {
-    int t = 0;
+// Tiles of a cluster-resident workgroup: its surfaces are packed into wavefronts whatever their lane counts (a
+// mixed tile carries a lane table, layout.hpp), in ascending order of k — what the tiling below does.
+int tiles_needed_packed(const int (&cnt)[kWave + 1]) {
+    int tiles = 0, lanes = 0;
     for (int k = 1; k <= kWave; k++)
-        if (cnt[k]) t += (cnt[k] + kWave / k - 1) / (kWave / k);
-    return t;
+        for (int q = 0; q < cnt[k]; q++) {
+            if (lanes + k > kWave) { tiles++; lanes = 0; }
+            lanes += k;
+        }
+    return tiles + (lanes > 0);
 }
 
 // What kind of kernel a surface needs (before the blocking factor M is chosen).
@@ -352,11 +356,11 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                     for (int64_t q = coff[r]; q < coff[r + 1] && ok; q++) {
                         if (is_small(csurf[q])) continue;
                         const int kk = (placed[csurf[q]].n + m - 1) / m;
-                        ok = kk >= 2 && kk <= kWave;
+                        ok = kk >= ((m == 8 && !any_cav && !mixed) ? 1 : 2) && kk <= kWave;  // (single-lane surfaces: 8 nodes per lane, no cavities)
                         if (ok) c_k[kk]++;
                     }
                     if (!ok) continue;
-                    const int nt_m = tiles_needed(c_k) + small_tiles(n_small);
+                    const int nt_m = tiles_needed_packed(c_k) + small_tiles(n_small);
                     if (nt_m > kFusedMaxWaves) continue;
                     const double t = cluster_ns(m, nt_m);
                     if (M == 0 || t <= best_cost) { M = m; best_cost = t; }
@@ -370,12 +374,12 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 ne += (zone_of_side(csurf[q], 0) >= 0) + (zone_of_side(csurf[q], 1) >= 0);
                 if (is_small(csurf[q])) continue;
                 const int k = (pl.n + M - 1) / M;
-                if (k > kWave || k < 2) { fits = false; break; }  // (the fused kernels have no single-lane path)
+                if (k > kWave || k < ((M == 8 && !any_cav && !mixed) ? 1 : 2)) { fits = false; break; }  // (single-lane surfaces: 8 nodes per lane, no cavities)
                 cnt[k]++;
                 nm |= cat[csurf[q]].nm;
             }
             const int nz = (int)czones[r].size();
-            if (!fits || tiles_needed(cnt) + small_tiles(n_small) > kFusedMaxWaves || nz > kFusedMaxZones ||
+            if (!fits || tiles_needed_packed(cnt) + small_tiles(n_small) > kFusedMaxWaves || nz > kFusedMaxZones ||
                 ne > kFusedMaxEntries)
                 continue;  // streamed
             if (!fuse_always) {
@@ -388,7 +392,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                     n_cav_small += cat[csurf[q]].kind == kSmallCav;
                     bytes += 32.0 * placed[csurf[q]].n + 152.0;
                 }
-                const int tiles = tiles_needed(cnt) + small_tiles(n_small);
+                const int tiles = tiles_needed_packed(cnt) + small_tiles(n_small);
                 // A small batch is bound by launches and latency, not by throughput: there the resident march wins
                 // with any blocking factor (one launch per march call instead of two or more per sub-timestep).
                 const bool small_batch = S <= 8192;
@@ -404,7 +408,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             // Workgroups of four tiles are the target (two of them share a compute unit, so one's zone balance —
             // a short serial section — overlaps the other's stencil work): clusters are merged only up to four
             // tiles; a cluster that needs five to eight gets a workgroup of its own.
-            if (o.blk < 0 || tiles_needed(merged) + small_tiles(o.nsmall + n_small) > 4 || o.nz + nz > kFusedMaxZones ||
+            if (o.blk < 0 || tiles_needed_packed(merged) + small_tiles(o.nsmall + n_small) > 4 || o.nz + nz > kFusedMaxZones ||
                 o.ne + ne > kFusedMaxEntries) {
                 o = Open();
                 o.blk = new_block(cls, mixed);
@@ -438,11 +442,11 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             if (M == 0) {
                 M = 4;
                 for (int m : {8, 16})
-                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= 2 && fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
+                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= ((m == 8 && !cav) ? 1 : 2) && fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
             const bool gains = tile_ns(M) * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
-            if (k > kWave || k < 2 || (M == 16 && cav) || (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
+            if (k > kWave || k < ((M == 8 && !cav) ? 1 : 2) || (M == 16 && cav) || (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
             pl.k = k;
         }
@@ -528,7 +532,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     int64_t node_cursor = 0, scratch_cursor = 0;
     int64_t dcur = 0;
     size_t pos = 0;
-    struct NodeMap { int64_t base; int Lk; int k; int M; int g; int tile; };  // per device surface
+    struct NodeMap { int64_t base; int Lk; int k; int M; int g; int tile; int lane0; };  // per device surface
     std::vector<int> blk_first_tile(blocks.size(), -1), blk_n_tiles(blocks.size(), 0);
     std::vector<int> blk_first_small(blocks.size(), -1), blk_n_small(blocks.size(), 0);
     std::vector<NodeMap> nmap(S);
@@ -539,17 +543,35 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         prev_cls = p0.cls;
         if (p0.cls < kNumFast) {
             const int M = kFastM[p0.cls], k = p0.k;
-            const int Gmax = kWave / k, Lk = Gmax * k;
+            // A workgroup of the cluster-resident march whose surfaces differ in their lane counts packs them into
+            // its wavefronts one after the other (mixed tiles, lane table behind the tile's class bytes); everything
+            // else keeps tiles of one lane count, floor(64 / k) surfaces each.
+            bool mixed_block = false;
+            if (p0.blk >= 0) {
+                for (size_t q = pos; q < (size_t)S && placed[order[q]].cls == p0.cls && placed[order[q]].blk == p0.blk; q++)
+                    mixed_block = mixed_block || placed[order[q]].k != k;
+            }
+            const int Gmax = kWave / k;
             size_t end = pos;
-            while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].k == k &&
-                   placed[order[end]].blk == p0.blk && (int)(end - pos) < Gmax)
-                end++;
+            int lanes = 0;
+            if (mixed_block) {
+                while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].blk == p0.blk &&
+                       lanes + placed[order[end]].k <= kWave) {
+                    lanes += placed[order[end]].k;
+                    end++;
+                }
+            } else {
+                while (end < (size_t)S && placed[order[end]].cls == p0.cls && placed[order[end]].k == k &&
+                       placed[order[end]].blk == p0.blk && (int)(end - pos) < Gmax)
+                    end++;
+            }
+            const int Lk = mixed_block ? lanes : Gmax * k;
             bool all_full = true;
-            for (size_t q = pos; q < end; q++) all_full = all_full && (placed[order[q]].n == k * M);
+            for (size_t q = pos; q < end; q++) all_full = all_full && (placed[order[q]].n == placed[order[q]].k * M);
             FastTile t;
             t.node_base = node_cursor;
             t.surf_base = (int32_t)dcur;
-            t.k = (int16_t)(k | (all_full ? 0x100 : 0));
+            t.k = (int16_t)((mixed_block ? (Lk | kTileMixedBit) : k) | (all_full ? 0x100 : 0));
             t.G = (int16_t)(end - pos);
             const int tile_index = (int)fast_tiles[p0.cls].size();
             fast_tiles[p0.cls].push_back(t);
@@ -559,14 +581,17 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             } else {
                 p.n_stream_tiles[p0.cls] = tile_index + 1;  // streamed tiles come first in every class
             }
+            int lane0 = 0;
             for (size_t q = pos; q < end; q++) {
                 const int64_t s = order[q];
+                const int ks = placed[s].k;
                 dev_of[s] = dcur;
                 orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, Lk, k, M, (int)(q - pos), tile_index};
+                nmap[dcur] = NodeMap{node_cursor, Lk, ks, M, (int)(q - pos), tile_index, lane0};
+                lane0 += ks;
                 dcur++;
             }
-            node_cursor += (int64_t)M * Lk;
+            node_cursor += (int64_t)M * Lk + (mixed_block ? kLaneTableSlots : 0);
             pos = end;
         } else {
             if (gen_tiles.empty()) p.gen_base = node_cursor;
@@ -595,7 +620,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 const int64_t s = order[q];
                 dev_of[s] = dcur;
                 orig_of[dcur] = s;
-                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos), (int)gen_tiles.size() - 1};
+                nmap[dcur] = NodeMap{node_cursor, kWave, 1, 0, (int)(q - pos), (int)gen_tiles.size() - 1, (int)(q - pos)};
                 dcur++;
             }
             node_cursor += (int64_t)n_max * kWave;
@@ -610,7 +635,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     auto node_index = [&](int64_t dsurf, int i) -> int64_t {
         const NodeMap &m = nmap[dsurf];
         if (m.M == 0) return m.base + (int64_t)i * kWave + m.g;
-        const int lane = m.g * m.k + i / m.M, j = i % m.M;
+        const int lane = m.lane0 + i / m.M, j = i % m.M;
         return m.base + ((int64_t)(j >> 1) * m.Lk + lane) * 2 + (j & 1);
     };
 
@@ -642,7 +667,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 for (int q = 0; q < nu; q++) if (pp[kPalV + q] == hU[idx]) uc = q;
                 if (uc < 0) { uc = nu; pp[kPalV + nu++] = hU[idx]; }
                 const NodeMap &m = nmap[dd];
-                const int lane = m.g * m.k + i / m.M, j = i % m.M;
+                const int lane = m.lane0 + i / m.M, j = i % m.M;
                 hCls[m.base + (int64_t)lane * m.M + j] = (uint8_t)(vc | (uc << 3));
             }
             if (gen) {
@@ -656,6 +681,23 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         node0_index[s] = node_index(dd, 0);
         nodeN_index[s] = node_index(dd, n - 1);
     }
+
+    // ---- lane tables of the mixed tiles: behind the tile's class bytes, one 16-bit entry per lane ----
+    for (int c = 0; c < kNumFast; c++)
+        for (const FastTile &ft : fast_tiles[c]) {
+            if (!(ft.k & kTileMixedBit)) continue;
+            const int M = kFastM[c], Lk = ft.k & 0xff;
+            uint8_t *tab = &hCls[ft.node_base + (int64_t)M * Lk];
+            int lane = 0;
+            for (int g = 0; g < ft.G; g++) {
+                const int ks = nmap[ft.surf_base + g].k;
+                for (int seg = 0; seg < ks; seg++, lane++) {
+                    const uint16_t e = (uint16_t)(g | (seg << 6) | (seg == ks - 1 ? kLaneLastBit : 0));
+                    tab[2 * lane] = (uint8_t)(e & 0xff);
+                    tab[2 * lane + 1] = (uint8_t)(e >> 8);
+                }
+            }
+        }
 
     // ---- cavity references of the CAV fast classes ----
     std::vector<int32_t> hCavRef;
@@ -811,7 +853,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 const int bi = placed[s].blk;
                 const NodeMap &m = nmap[dev_of[s]];
                 // fast-path surfaces: the first / last lane of the surface owns the side; small surfaces: their lane
-                const int lane = (m.M == 0) ? m.g : (side ? (m.g * m.k + m.k - 1) : (m.g * m.k));
+                const int lane = (m.M == 0) ? m.g : (side ? (m.lane0 + m.k - 1) : m.lane0);
                 const int wave_in_block = (m.M == 0) ? blk_n_tiles[bi] + (m.tile - blk_first_small[bi])
                                                      : (m.tile - blk_first_tile[bi]);
                 const uint32_t slot = (uint32_t)(side * kWave * blk_fw[bi] + wave_in_block * kWave + lane);
@@ -926,6 +968,9 @@ void find_clusters(const heat_batch_desc *d, std::vector<int32_t> &cluster_of_su
 }
 
 // ---------------------------------------------------------------------------
+// the cluster-resident march runs surfaces of one lane in the 8-node classes without cavities only (kernels.hip)
+static bool single_lane_class(int c) { return kFastM[c] == 8 && !kFastCAV[c]; }
+
 int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
 #define PLAN_REQUIRE(cond, ...) \
     do { if (!(cond)) return failp(err, HEAT_E_SIZE, "plan check failed: " __VA_ARGS__); } while (0)
@@ -948,30 +993,46 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
         PLAN_REQUIRE(p.n_stream_tiles[c] >= 0 && p.n_stream_tiles[c] <= (int)p.fast_tiles[c].size(), "class %d: streamed tiles", c);
         for (size_t t = 0; t < p.fast_tiles[c].size(); t++) {
             const FastTile &ft = p.fast_tiles[c][t];
-            const int k = ft.k & 0xff;
-            PLAN_REQUIRE(k >= 1 && k <= kWave && ft.G >= 1 && ft.G * k <= kWave, "class %d tile %zu: k %d G %d", c, t, k, (int)ft.G);
-            const int Lk = (kWave / k) * k;
-            PLAN_REQUIRE(ft.node_base >= 0 && ft.node_base + (int64_t)M * Lk <= p.node_slots && ft.node_base % 2 == 0,
+            const bool mixed = (ft.k & kTileMixedBit) != 0;
+            const int k = ft.k & 0xff;  // lanes per surface; mixed: lanes of the tile
+            PLAN_REQUIRE(k >= 1 && k <= kWave && ft.G >= 1 && (mixed ? ft.G <= k : ft.G * k <= kWave), "class %d tile %zu: k %d G %d", c, t, k, (int)ft.G);
+            const int Lk = mixed ? k : (kWave / k) * k;
+            const int64_t extent = (int64_t)M * Lk + (mixed ? kLaneTableSlots : 0);
+            PLAN_REQUIRE(ft.node_base >= 0 && ft.node_base + extent <= p.node_slots && ft.node_base % 2 == 0,
                          "class %d tile %zu: node range", c, t);
-            PLAN_REQUIRE(ft.node_base + (int64_t)M * Lk <= p.gen_base, "class %d tile %zu reaches into the general group", c, t);
-            ranges.push_back({ft.node_base, ft.node_base + (int64_t)M * Lk});
+            PLAN_REQUIRE(ft.node_base + extent <= p.gen_base, "class %d tile %zu reaches into the general group", c, t);
+            ranges.push_back({ft.node_base, ft.node_base + extent});
             PLAN_REQUIRE(ft.surf_base >= 0 && ft.surf_base + ft.G <= S, "class %d tile %zu: surfaces", c, t);
+            PLAN_REQUIRE(!mixed || (kFastPAL[c] && !p.cls.empty()), "mixed tile outside the palette classes");
+            int lane0 = 0;
             for (int g = 0; g < ft.G; g++) {
                 const int64_t dd = ft.surf_base + g;
                 PLAN_REQUIRE(!covered[dd], "device surface %lld in two tiles", (long long)dd);
                 covered[dd] = 1;
                 const int n = p.meta[dd];
-                PLAN_REQUIRE(n >= 1 && (n + M - 1) / M == k, "class %d tile %zu: surface of %d nodes in %d lanes of %d", c, t, n, k, M);
-                if (ft.k & 0x100) PLAN_REQUIRE(n == k * M, "class %d tile %zu marked full", c, t);
+                const int ks = (n + M - 1) / M;
+                PLAN_REQUIRE(n >= 1 && (mixed ? lane0 + ks <= Lk : ks == k), "class %d tile %zu: surface of %d nodes, %d lanes of %d", c, t, n, k, M);
+                if (!mixed) lane0 = g * k;
+                if (ft.k & 0x100) PLAN_REQUIRE(n == ks * M, "class %d tile %zu marked full", c, t);
+                if (mixed) {
+                    const uint8_t *tab = &p.cls[ft.node_base + (int64_t)M * Lk];
+                    for (int seg = 0; seg < ks; seg++) {
+                        const int e = tab[2 * (lane0 + seg)] | (tab[2 * (lane0 + seg) + 1] << 8);
+                        PLAN_REQUIRE((e & 63) == g && ((e >> 6) & 63) == seg && ((e & kLaneLastBit) != 0) == (seg == ks - 1),
+                                     "class %d tile %zu: lane table entry of lane %d", c, t, lane0 + seg);
+                    }
+                }
                 if (kFastPAL[c]) {
                     PLAN_REQUIRE(!p.cls.empty(), "palette class without class bytes");
                     for (int i = 0; i < n; i++) {
-                        const int lane = g * k + i / M, j = i % M;
+                        const int lane = lane0 + i / M, j = i % M;
                         const uint8_t cb = p.cls[ft.node_base + (int64_t)lane * M + j];
                         PLAN_REQUIRE((cb & 7) < kPalV && (cb >> 3) < kPalU, "class byte %d", (int)cb);
                     }
                 }
+                if (mixed) lane0 += ks;
             }
+            PLAN_REQUIRE(!mixed || lane0 == Lk, "class %d tile %zu: %d lanes used, %d declared", c, t, lane0, Lk);
         }
     }
     PLAN_REQUIRE(p.n_small_plain_tiles <= p.n_small_tiles && p.n_small_tiles <= (int)p.gen_tiles.size(), "small tile counts");
@@ -1049,7 +1110,9 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
                 }
                 for (int q = 0; q < fb.n_tiles; q++) {
                     const FastTile &ft = p.fast_tiles[c][fb.first_tile + q];
-                    PLAN_REQUIRE((ft.k & 0xff) >= 2, "fused tile of single-lane surfaces");
+                    if (!single_lane_class(c) || (g2 >> 1))
+                        for (int g = 0; g < ft.G; g++)
+                            PLAN_REQUIRE(p.meta[ft.surf_base + g] > kFastM[c], "fused tile with a single-lane surface (class %d)", c);
                     fused_surfaces += ft.G;
                     for (int g = 0; g < ft.G; g++)
                         for (int side = 0; side < 2; side++) {

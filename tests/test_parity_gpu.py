@@ -572,6 +572,11 @@ def test_cluster_resident_march_matches_the_oracle_and_the_streamed_march(oracle
     registers, zone balance in LDS); the others are streamed beside them. Same results as the oracle (1e-9) and as
     the all-streamed march (no_fusion), also when the march is cut into several calls."""
     md, st = mdl.clustered_massive(1500, Z=60, dt=45.0, seed=11 + npl)
+    # the first sixteen zones are chained by some of their walls into one cluster of ~400 walls: too large for a
+    # workgroup, it is streamed beside the others
+    chain = (md["back_zone"] < 16) & (np.arange(1500) % 3 == 0)
+    md["front_kind"] = np.where(chain, mdl.SPACE, md["front_kind"]).astype(np.int32)
+    md["front_zone"] = np.where(chain, (md["back_zone"] + 1) % 16, md["front_zone"]).astype(np.int32)
     w = mdl.weather_series(23, 45.0, wind_speed=3.5, wind_deg=120.0)
     a0 = np.linspace(0., 60., 60)
     b0 = np.linspace(0., 2., 60)
