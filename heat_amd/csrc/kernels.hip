@@ -580,7 +580,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             for (int j = 0; j < M; j++) {
                 const unsigned int cbj = (cw[j >> 2] >> (8 * (j & 3))) & 0xff;
                 V[j] = mp[cbj & (kPalV - 1)];
-                U[j] = mp[kPalV + (cbj >> 3)];
+                U[j] = mp[kPalV + ((cbj >> 3) & (kPalU - 1))];  // (bits 5-6: no-mass chunk marks, see below)
             }
         }
         if constexpr (kVinLds) {
@@ -725,6 +725,9 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     double hF = 0.0, qF = 0.0, hB = 0.0, qB = 0.0;
     // add_face returns the face conductance and source through h_out / q_out (the caller files them
     // under front or back with selects: storing through a runtime side index lands in scratch).
+    // (NM: the terms of a face are kept for the no-mass chunk that may sit at it, below)
+    double fF_hs = 0.0, fF_rhs = 0.0, fF_rad = 0.0, fF_air = 0.0, fF_sol = 0.0;  // front face of this lane's surface
+    double fB_hs = 0.0, fB_rhs = 0.0, fB_rad = 0.0, fB_air = 0.0, fB_sol = 0.0;  // back face
     auto add_face = [&](const SideConst &cc, const SideDyn &dd, bool back, double air_t, double rad_t, double forced,
                         int rec, bool use_front_T, double &h_out, double &q_out) {
         h_out = 0.0;
@@ -734,53 +737,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
         const double sol = dd.solar;                        // absorbed: alpha * irradiance, formed at upload
         if constexpr (NM) {
-            // One-node no-mass chunk at this face (discretization.rs:658-697 for nnodes == 1):
-            //   K = (0 - h_face) - u_inner,  q = (q_face + u_inner * T_inner) + solar,  x = -q / K,
-            //   T <- (T + x) / 2 until the error stops shrinking or err < tol (surface.rs:836-895).
+            fF_hs = back ? fF_hs : hs; fF_rhs = back ? fF_rhs : rhs; fF_rad = back ? fF_rad : rad_t;
+            fF_air = back ? fF_air : air_t; fF_sol = back ? fF_sol : sol;
+            fB_hs = back ? hs : fB_hs; fB_rhs = back ? rhs : fB_rhs; fB_rad = back ? rad_t : fB_rad;
+            fB_air = back ? air_t : fB_air; fB_sol = back ? sol : fB_sol;
+            // a no-mass face node belongs to a chunk solved below; V == 0: it takes no part in the RK4
             const double vface = back ? V_last() : Vat(0);
-            if (nm_on && active && vface == 0.0 && nn >= 2) {
-                double u_in, t_in;
-                if (!back) {
-                    u_in = U[0];
-                    t_in = T[1 % M];
-                } else {
-                    // inner neighbour of the last node: previous node of this lane, or of the previous lane
-                    double up = UL, tp = T_prev_last;
-#pragma unroll
-                    for (int j = 1; j < M; j++) {
-                        up = (j == jl) ? U[j - 1] : up;
-                        tp = (j == jl) ? T[j - 1] : tp;
-                    }
-                    u_in = up;
-                    t_in = tp;
-                }
-                double Tc = back ? pick_last(T) : T[0];
-                const double dg = (0.0 - hs) - u_in;
-                const double nb = u_in * t_in;
-                double old_err = 99999.;
-                int count = 0;
-                for (;;) {
-                    const double qf = air_t * hs + rhs * (rad_t - Tc);
-                    const double q = ((back ? (nb + qf) : (qf + nb)) + sol) * -1.;
-                    const double x = q / dg;
-                    const double err = fabs(x - Tc);
-                    nm_passes++;
-                    if (err > old_err) break;                            // surface.rs:842-848
-                    if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
-                    Tc = (Tc + x) * 0.5;
-                    const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
-                    if (err < tol) break;
-                    old_err = err;
-                    count++;
-                }
-                if (!back) {
-                    T[0] = Tc;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < M; j++) T[j] = (j == jl) ? Tc : T[j];
-                }
-                return;  // V == 0: the node takes no part in the RK4 below
-            }
+            if (nm_on && vface == 0.0 && nn >= 2) return;
         }
         const double tface = back ? pick_last(T) : T[0];
         h_out = hs;
@@ -807,6 +770,95 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             b_cos = cb2.cos_eff;
             b_neg = cb2.alpha;
             add_face(cb2, db2, true, b_air, b_rad, b_forced, S + d, b_useF, hB, qB);
+        }
+    }
+
+    if constexpr (NM) {
+        // ---- no-mass chunks (march_nomass, surface.rs:790-898), before the massive nodes march (surface.rs:950-965) ----
+        // A chunk is one or two consecutive no-mass nodes between massive nodes and / or a face: a thin facing, two
+        // light layers at a face (render on insulation), an insulation layer and an air gap inside a cavity wall. Its
+        // nodes sit in one lane; the class byte of its first node says so (bits 5-6: 1 or 2 nodes; per-node-array
+        // classes know one-node facings only). Every pass rebuilds the chunk's K and q as get_k_q does
+        // (discretization.rs:596-700: interior segments, then the front term, then the back term), solves K x = -q
+        // (mut_n_diag_gaussian) and halves the distance, T <- (T + x) / 2, with the reference's exit rules.
+        const double T_next_first = from_next_lane(T[0]);  // (wave-wide exchange, outside the divergent code)
+        unsigned int starts = 0;                            // two bits per local node
+        if (nm_on && active) {
+            if constexpr (PAL) {
+#pragma unroll
+                for (int j = 0; j < M; j++) starts |= (((cw[j >> 2] >> (8 * (j & 3))) >> 5) & 3u) << (2 * j);
+            } else {
+                if (is_first && Vat(0) == 0.0 && nn >= 2) starts |= 1u;
+                if (is_last && V_last() == 0.0 && nn >= 2 && !(is_first && jl == 0)) starts |= 1u << (2 * jl);
+            }
+        }
+        while (__any(starts != 0)) {
+            if (starts != 0) {
+                const int j0 = (__ffs((int)starts) - 1) >> 1;
+                const int cn = (int)((starts >> (2 * j0)) & 3u);  // nodes of the chunk: 1 or 2
+                starts &= ~(3u << (2 * j0));
+                const int j1 = j0 + cn - 1;                       // its last node
+                // operands: the chunk's temperatures, its neighbours' (a lane further where the chunk touches the
+                // lane's end), the conductances around and inside it
+                double ta = T[0], tb = T[0], tp = T_prev_last, tn = T_next_first, up = UL, ui = 0.0, un = 0.0;
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    ta = (j == j0) ? T[j] : ta;
+                    tb = (j == j1) ? T[j] : tb;
+                    if (j + 1 < M) tp = (j + 1 == j0) ? T[j] : tp;
+                    if (j > 0) tn = (j == j1 + 1) ? T[j] : tn;
+                    if (j + 1 < M) up = (j + 1 == j0) ? U[j] : up;
+                    ui = (j == j0) ? U[j] : ui;
+                    un = (j == j1) ? U[j] : un;
+                }
+                const bool faceL = is_first && j0 == 0;           // the chunk starts at the front face
+                const bool faceR = is_last && j1 == jl;           // ... ends at the back face
+                const double hL = faceL ? fF_hs : up, hR = faceR ? fB_hs : un;
+                const double solA = faceL ? fF_sol : 0.0;
+                const double solB = faceR ? fB_sol : 0.0;         // (cn == 1 at the back face: added to node a)
+                double old_err = 99999.;
+                int count = 0;
+                for (;;) {
+                    const double t_last = (cn == 2) ? tb : ta;
+                    const double qL = faceL ? (fF_air * fF_hs + fF_rhs * (fF_rad - ta)) : (up * tp);
+                    const double qR = faceR ? (fB_air * fB_hs + fB_rhs * (fB_rad - t_last)) : (un * tn);
+                    double x0, x1 = 0.0, err;
+                    if (cn == 1) {
+                        const double dg = (0.0 + -hL) + -hR;
+                        const double q = (((0.0 + qL) + qR) + (solA + solB)) * -1.;
+                        x0 = q / dg;
+                        err = fabs(x0 - ta);
+                    } else {
+                        const double u = ui;
+                        double dg0 = 0.0 + -u, dg1 = 0.0 - u;
+                        const double up0 = 0.0 + u, lo1 = 0.0 + u;
+                        dg0 += -hL;
+                        dg1 += -hR;
+                        const double q0 = ((0.0 + qL) + solA) * -1.;
+                        double q1 = ((0.0 + qR) + solB) * -1.;
+                        const double f = lo1 / dg0;                // mut_n_diag_gaussian(q, 3)
+                        dg1 -= f * up0;
+                        q1 -= f * q0;
+                        x1 = q1 / dg1;
+                        x0 = (q0 - up0 * x1) / dg0;
+                        err = fabs(x0 - ta) + fabs(x1 - tb);
+                    }
+                    nm_passes++;
+                    if (err > old_err) break;                            // surface.rs:842-848
+                    if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
+                    ta = (ta + x0) * 0.5;
+                    if (cn == 2) tb = (tb + x1) * 0.5;
+                    const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
+                    if (err / (double)cn < tol) break;
+                    old_err = err;
+                    count++;
+                }
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    T[j] = (j == j0) ? ta : T[j];
+                    if (j > 0) T[j] = (cn == 2 && j == j1) ? tb : T[j];
+                }
+            }
         }
     }
 

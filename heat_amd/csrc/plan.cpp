@@ -51,16 +51,18 @@ int tiles_needed_packed(const int (&cnt)[kWave + 1]) {
 // What kind of kernel a surface needs (before the blocking factor M is chosen).
 struct Category {
     int kind;  // kSmall, kSmallCav, kGeneral, or 0 = fast path
-    int nm;    // fast: has a no-mass facing node
+    int nm;    // fast: has no-mass chunks (one or two nodes each, between massive nodes and / or a face)
     int ncav;  // fast: gas cavities between massive nodes
     int pal;   // fast: the per-node constants fit a palette
+    int m_ok;  // fast: blocking factors whose lanes hold every chunk whole (bit 0: 4, bit 1: 8, bit 2: 16 nodes per lane)
 };
+inline int m_bit(int M) { return M == 4 ? 1 : (M == 8 ? 2 : 4); }
 
 // Decides whether a surface can take the register-resident fast path:
 // solid conductances only, solar absorbed at the two faces only, every interior node massive; the
 // face nodes may be no-mass facings (each then is an isolated one-node no-mass chunk).
 Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch_options &opt) {
-    Category r{kGeneral, 0, 0, 0};
+    Category r{kGeneral, 0, 0, 0, 7};
     if (opt.force_general) return r;
     const int64_t o = d->node_offset[s];
     if (n <= 4) {
@@ -75,13 +77,10 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
         }
     }
     if (n < 2) return r;
-    int nm = 0, ncav = 0;
+    int nm = 0, ncav = 0, m_ok = 7;
+    bool facings_only = true;
     auto is_cav = [&](int i) { return d->seg_cavity && d->n_cavities > 0 && d->seg_cavity[o + i] >= 0; };
     for (int i = 0; i < n; i++) {
-        if (d->mass[o + i] < kMassThreshold) {
-            if (i != 0 && i != n - 1) return r;                        // no-mass node inside
-            nm = 1;
-        }
         if (is_cav(i)) {
             // a cavity on the fast path sits between two massive nodes (its conductance is then needed
             // once per sub-timestep, not once per pass of a no-mass loop)
@@ -91,7 +90,29 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
         if (i > 0 && d->front_alpha[o + i] != 0.0) return r;           // solar absorbed inside
         if (i < n - 1 && d->back_alpha[o + i] != 0.0) return r;
     }
-    if (n == 2 && d->mass[o] < kMassThreshold && d->mass[o + 1] < kMassThreshold) return r;  // 2-node chunk
+    // No-mass chunks (get_chunks, discretization.rs:144-160): one or two nodes each — a thin facing, two light
+    // layers at a face, two light layers inside a cavity wall; longer runs go to the catch-all kernel. A two-node
+    // chunk has to sit in one lane, and a lane solves two chunks at most.
+    for (int i = 0; i < n;) {
+        if (d->mass[o + i] >= kMassThreshold) { i++; continue; }
+        int e = i;
+        while (e < n && d->mass[o + e] < kMassThreshold) e++;
+        if (e - i > 2) return r;
+        nm = 1;
+        if (!(e - i == 1 && (i == 0 || i == n - 1))) facings_only = false;
+        for (int M : {4, 8, 16})
+            if (e - i == 2 && i / M != (i + 1) / M) m_ok &= ~m_bit(M);
+        i = e;
+    }
+    for (int M : {4, 8, 16}) {
+        int in_lane = 0, lane = -1;
+        for (int i = 0; i < n; i++) {
+            const bool start = d->mass[o + i] < kMassThreshold && (i == 0 || d->mass[o + i - 1] >= kMassThreshold);
+            if (i / M != lane) { lane = i / M; in_lane = 0; }
+            if (start && ++in_lane > 2) m_ok &= ~m_bit(M);
+        }
+    }
+    if (m_ok == 0) return r;
     // Palette form when the wall has few distinct constants (entry 0 of each palette is 0.0).
     int pal = opt.no_palette ? 0 : 1;
     if (pal) {
@@ -112,10 +133,12 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
         }
     }
     if (ncav > 0 && !pal) return r;  // the cavity variant exists in palette form only
+    if (nm && !facings_only && !pal) return r;  // chunks other than one-node facings are marked in the class bytes
     r.kind = 0;
     r.nm = nm;
     r.ncav = ncav;
     r.pal = pal;
+    r.m_ok = m_ok;
     return r;
 }
 
@@ -130,12 +153,14 @@ double padded_cost(int n, int M) {
 // nm: the wall has a no-mass facing. Its 16-node variant (k_surfaces_fast<16, 1, 1, 0>) needs 266 registers — one
 // wavefront per SIMD, 3.1 TB/s against 6.2 for the all-massive walls (profiles/README.md, round 2) — so walls with
 // facings take 8 nodes per lane at most.
-int choose_M(int n, int nm, const heat_batch_options &opt) {
-    if (opt.nodes_per_lane != 0) return opt.nodes_per_lane;
-    int M = 4;
-    for (int m : {8, 16})
-        if (!(nm && m == 16) && padded_cost(n, m) < padded_cost(n, M)) M = m;
-    return M;
+int choose_M(int n, int nm, int m_ok, const heat_batch_options &opt) {
+    if (opt.nodes_per_lane != 0) return (m_ok & m_bit(opt.nodes_per_lane)) ? opt.nodes_per_lane : 0;
+    int M = 0;
+    for (int m : {4, 8, 16}) {
+        if ((nm && m == 16 && (m_ok & 3)) || !(m_ok & m_bit(m))) continue;
+        if (M == 0 || padded_cost(n, m) < padded_cost(n, M)) M = m;
+    }
+    return M;  // 0: no blocking factor holds the wall's chunks -> catch-all
 }
 
 int fast_class(int M, const Category &c) { return (M == 4 ? 0 : (M == 8 ? 6 : 12)) + c.nm * 3 + (c.ncav > 0 ? 2 : c.pal); }
@@ -224,8 +249,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         cat[s] = categorize(d, s, n, opt);
         int cls = cat[s].kind, k = 1;
         if (cat[s].kind == 0) {
-            const int M = choose_M(n, cat[s].nm, opt);
-            k = (n + M - 1) / M;
+            const int M = choose_M(n, cat[s].nm, cat[s].m_ok, opt);
+            k = M ? (n + M - 1) / M : kWave + 1;
             cls = (k > kWave) ? kGeneral : fast_class(M, cat[s]);
             if (k > kWave) { cat[s].kind = kGeneral; k = 1; }
         }
@@ -244,7 +269,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         for (int mi : {0, 2}) {
             if (nodes_by_M[mi] == 0 || nodes_by_M[mi] * 12 >= all_nodes || nodes_by_M[1] == 0) continue;
             for (int64_t s = 0; s < S; s++)
-                if (placed[s].cls < kNumFast && placed[s].cls / 6 == mi && (placed[s].n + 7) / 8 <= kWave) {
+                if (placed[s].cls < kNumFast && placed[s].cls / 6 == mi && (placed[s].n + 7) / 8 <= kWave && (cat[s].m_ok & m_bit(8))) {
                     placed[s].k = (placed[s].n + 7) / 8;
                     placed[s].cls = fast_class(8, cat[s]);
                 }
@@ -356,7 +381,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                     for (int64_t q = coff[r]; q < coff[r + 1] && ok; q++) {
                         if (is_small(csurf[q])) continue;
                         const int kk = (placed[csurf[q]].n + m - 1) / m;
-                        ok = kk >= ((m == 8 && !any_cav && !mixed) ? 1 : 2) && kk <= kWave;  // (single-lane surfaces: 8 nodes per lane, no cavities)
+                        ok = kk >= ((m == 8 && !any_cav && !mixed) ? 1 : 2) && kk <= kWave &&  // (single-lane surfaces: 8 nodes per lane, no cavities)
+                             (cat[csurf[q]].m_ok & m_bit(m)) != 0;                              // (no-mass chunks whole in their lanes)
                         if (ok) c_k[kk]++;
                     }
                     if (!ok) continue;
@@ -374,7 +400,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 ne += (zone_of_side(csurf[q], 0) >= 0) + (zone_of_side(csurf[q], 1) >= 0);
                 if (is_small(csurf[q])) continue;
                 const int k = (pl.n + M - 1) / M;
-                if (k > kWave || k < ((M == 8 && !any_cav && !mixed) ? 1 : 2)) { fits = false; break; }  // (single-lane surfaces: 8 nodes per lane, no cavities)
+                if (k > kWave || k < ((M == 8 && !any_cav && !mixed) ? 1 : 2) || !(cat[csurf[q]].m_ok & m_bit(M))) { fits = false; break; }
                 cnt[k]++;
                 nm |= cat[csurf[q]].nm;
             }
@@ -400,7 +426,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 if (!small_batch && cluster_ns(M, tiles) > 0.85 * (bytes / kStreamBytesPerNs + kZoneNs * nz))
                     continue;                                                                       // streamed
             }
-            Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1};
+            Category cc{0, mixed ? 1 : nm, (mixed ? (M < 16) : any_cav) ? 1 : 0, 1, 7};
             const int cls = fast_class(M, cc);
             Open &o = open[2 * cls + (mixed ? 1 : 0)];
             int merged[kWave + 1];
@@ -442,12 +468,14 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             if (M == 0) {
                 M = 4;
                 for (int m : {8, 16})
-                    if (!(m == 16 && cav) && (pl.n + m - 1) / m >= ((m == 8 && !cav) ? 1 : 2) && fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
+                    if (!(m == 16 && cav) && (cat[s].m_ok & m_bit(m)) && (pl.n + m - 1) / m >= ((m == 8 && !cav) ? 1 : 2) &&
+                        fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
             const bool gains = tile_ns(M) * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
-            if (k > kWave || k < ((M == 8 && !cav) ? 1 : 2) || (M == 16 && cav) || (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
-            pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1});
+            if (k > kWave || k < ((M == 8 && !cav) ? 1 : 2) || (M == 16 && cav) || !(cat[s].m_ok & m_bit(M)) ||
+                (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
+            pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1, 7});
             pl.k = k;
         }
         std::stable_sort(lone.begin(), lone.end(), [&](int64_t x, int64_t y) {
@@ -681,6 +709,22 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         node0_index[s] = node_index(dd, 0);
         nodeN_index[s] = node_index(dd, n - 1);
     }
+
+    // ---- no-mass chunk marks: bits 5-6 of the class byte of a chunk's first node = its node count (kernels.hip) ----
+    if (!hCls.empty())
+        for (int64_t dd = 0; dd < S; dd++) {
+            const int64_t s = orig_of[dd];
+            if (!(placed[s].cls < kNumFast && kFastPAL[placed[s].cls] && cat[s].nm)) continue;
+            const int64_t o = d->node_offset[s];
+            const NodeMap &m = nmap[dd];
+            for (int i = 0; i < placed[s].n;) {
+                if (d->mass[o + i] >= kMassThreshold) { i++; continue; }
+                int e = i;
+                while (e < placed[s].n && d->mass[o + e] < kMassThreshold) e++;
+                hCls[m.base + (int64_t)(m.lane0 + i / m.M) * m.M + i % m.M] |= (uint8_t)((e - i) << 5);
+                i = e;
+            }
+        }
 
     // ---- lane tables of the mixed tiles: behind the tile's class bytes, one 16-bit entry per lane ----
     for (int c = 0; c < kNumFast; c++)
@@ -1027,7 +1071,8 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
                     for (int i = 0; i < n; i++) {
                         const int lane = lane0 + i / M, j = i % M;
                         const uint8_t cb = p.cls[ft.node_base + (int64_t)lane * M + j];
-                        PLAN_REQUIRE((cb & 7) < kPalV && (cb >> 3) < kPalU, "class byte %d", (int)cb);
+                        PLAN_REQUIRE((cb & 7) < kPalV && ((cb >> 3) & 3) < kPalU && (cb >> 5) <= 2 &&
+                                     ((cb >> 5) != 2 || j + 1 < M), "class byte %d", (int)cb);
                     }
                 }
                 if (mixed) lane0 += ks;

@@ -143,6 +143,65 @@ def test_config2_and_config5_at_baseline_size(oracle):
     assert_state_close(md, ref, got)
 
 
+@pytest.mark.parametrize("npl", [0, 4, 8, 16])
+def test_nomass_chunks_inside_the_wall_and_of_two_nodes_on_the_fast_path(oracle, npl):
+    """ThermalSurfaceData::march solves every no-mass chunk wherever it sits (surface.rs:950-965); get_chunks
+    (discretization.rs:144-160) makes them of any two adjacent light layers: render on insulation at a face (two
+    nodes), an insulation layer and an air gap inside a cavity wall (one node between two massive chunks). These run
+    in the register kernel — nothing is left to the one-lane-per-surface catch-all — with the oracle's pass counts."""
+    conc = dict(thickness=0.2, k=0.816, rho=1700., cp=800.)
+    brick = dict(thickness=0.1, k=0.6, rho=1600., cp=840.)
+    poly = dict(thickness=0.02, k=0.0252, rho=17.5, cp=2400.)
+    wool = dict(thickness=0.05, k=0.04, rho=30., cp=1000.)
+    walls = {"render on insulation outside": [poly, wool, conc],
+             "insulation and lining inside": [conc, wool, poly],
+             "cavity wall": [brick, wool, poly, brick],
+             "both": [poly, wool, conc, wool, poly],
+             "facing and cavity": [poly, brick, poly, poly, conc, poly]}   # (three conductances: the palette's limit)
+    mds, states = [], []
+    for name, lay in walls.items():
+        lay = [dict(L, front_thermal_abs=0.2, back_thermal_abs=0.2, front_solar_abs=0.6, back_solar_abs=0.6) for L in lay]
+        d = oracle.discretize(lay, 180., 0.04, 60., 1., math.pi / 2)
+        _, nomass = oracle.get_chunks(d["mass"])
+        assert nomass and max(e - i for i, e in nomass) <= 2, (name, nomass)
+        assert any(e - i == 2 or (i > 0 and e < d["n_nodes"]) for i, e in nomass), (name, nomass)   # not just one-node facings
+        md, st = surfaces_model(d, 180. / d["tstep_subdivision"] / 2., mdl.OUTDOOR, mdl.SPACE, n_zones=2, zone_volume=[300., 200.],
+                                back_zone=1, front_emis=0.2, back_emis=0.2, area=12., perimeter=14., cos_tilt=0.0,
+                                normal=(0.6, -0.8, 0.), copies=37)
+        mds.append(md); states.append(st)
+    dt = min(m["dt"] for m in mds)
+    # one model of all of them (same dt), every second wall between the two zones
+    md = mdl.empty(sum(m["n_surfaces"] for m in mds), 2, dt)
+    off = [0]
+    for m in mds:
+        off.extend((off[-1] + np.asarray(m["node_offset"][1:])).tolist())
+    md["node_offset"] = np.asarray(off, dtype=np.int64)
+    for k in ("mass", "uvalue", "front_alpha", "back_alpha"):
+        md[k] = np.concatenate([m[k] for m in mds])
+    for k in mdl.PER_SURFACE_F64 + mdl.PER_SURFACE_I32:
+        md[k] = np.concatenate([m[k] for m in mds])
+    S = md["n_surfaces"]
+    rng = np.random.default_rng(5 + npl)
+    sp = np.arange(S) % 2 == 1
+    md["front_kind"] = np.where(sp, mdl.SPACE, mdl.OUTDOOR).astype(np.int32)
+    md["front_zone"] = np.zeros(S, dtype=np.int32)
+    md["cos_tilt"] = rng.choice([0.0, 0.707, -1.0], S)
+    md["zone_volume"] = np.array([300., 200.])
+    st = mdl.layout_state(md)
+    mdl.perturb_initial_temperatures(md, st, rng)
+    st[md["solar_front_slot"]] = rng.uniform(0., 600., S)
+    st[md["solar_back_slot"]] = rng.uniform(0., 50., S)
+    mdl.set_ir_from_air(md, st, 8.0)
+    w = mdl.weather_series(30, dt, wind_speed=4.0, wind_deg=40.0)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, np.array([40., 0.]), np.array([1., 0.5]),
+                                                  nodes_per_lane=npl)
+    assert counts[4] == 0 or npl != 0, counts          # the planner's own choice leaves nothing to the catch-all
+    if npl != 0:
+        assert counts[4] < S                            # (a forced blocking factor may cut a two-node chunk in two)
+    assert iters == gpu_iters and iters > 0
+    assert_state_close(md, ref, got)
+
+
 def test_reference_unit_test_walls_through_the_abi(oracle):
     # test_march_massive_1 / test_march_nomass (surface.rs:1087-1443) with the debug hs overrides
     lay = [dict(thickness=20. / 1000., **BRICKWORK)]
