@@ -520,7 +520,7 @@ int rebuild_unified(heat_batch *b) {
                 n_classes += n > 0;
                 for (int t = 0; t < n; t++) {
                     FastTile ft = b->h_tiles_cur[c][t];
-                    ft.k = (int16_t)((ft.k & (0x1ff | kTileMixedBit)) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
+                    ft.k = (int16_t)((ft.k & (0x1ff | kTileMixedBit | kTileChunkyBit)) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
                     fast.push_back(ft);
                 }
             }

@@ -498,6 +498,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     double *const s_zT = fl.zT;
     (void)s_hT; (void)s_zT; (void)s_V; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
     const bool mixed = PAL && (tile.k & kTileMixedBit) != 0;  // (wave-uniform) surfaces of different lane counts
+    // (wave-uniform) the tile holds no-mass chunks other than one-node facings: chunks inside the wall, of two nodes
+    // (streamed variants only: the cluster-resident march leaves clusters with such walls to the streamed kernels — the
+    // chunk loop's registers would cost every fused NM variant, used or not)
+    const bool chunky = NM && PAL && !FUSED && (tile.k & kTileChunkyBit) != 0;
     const int k = tile.k & 0xff;                              // lanes per surface; mixed: lanes of the tile
     const bool full = (tile.k & 0x100) != 0;
     const int G = tile.G;
@@ -737,13 +741,62 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
         const double sol = dd.solar;                        // absorbed: alpha * irradiance, formed at upload
         if constexpr (NM) {
-            fF_hs = back ? fF_hs : hs; fF_rhs = back ? fF_rhs : rhs; fF_rad = back ? fF_rad : rad_t;
-            fF_air = back ? fF_air : air_t; fF_sol = back ? fF_sol : sol;
-            fB_hs = back ? hs : fB_hs; fB_rhs = back ? rhs : fB_rhs; fB_rad = back ? rad_t : fB_rad;
-            fB_air = back ? air_t : fB_air; fB_sol = back ? sol : fB_sol;
-            // a no-mass face node belongs to a chunk solved below; V == 0: it takes no part in the RK4
+            if constexpr (PAL && !FUSED) {
+                fF_hs = back ? fF_hs : hs; fF_rhs = back ? fF_rhs : rhs; fF_rad = back ? fF_rad : rad_t;
+                fF_air = back ? fF_air : air_t; fF_sol = back ? fF_sol : sol;
+                fB_hs = back ? hs : fB_hs; fB_rhs = back ? rhs : fB_rhs; fB_rad = back ? rad_t : fB_rad;
+                fB_air = back ? air_t : fB_air; fB_sol = back ? sol : fB_sol;
+            }
+            // a no-mass face node is (part of) a chunk; V == 0: it takes no part in the RK4
             const double vface = back ? V_last() : Vat(0);
-            if (nm_on && vface == 0.0 && nn >= 2) return;
+            if (nm_on && active && vface == 0.0 && nn >= 2) {
+                if (chunky) return;  // solved with the tile's other chunks below
+                // The common case, a tile whose only chunks are one-node facings — solved right here
+                // (discretization.rs:658-697 for nnodes == 1):
+                //   K = (0 - h_face) - u_inner,  q = (q_face + u_inner * T_inner) + solar,  x = -q / K,
+                //   T <- (T + x) / 2 until the error stops shrinking or err < tol (surface.rs:836-895).
+                double u_in, t_in;
+                if (!back) {
+                    u_in = U[0];
+                    t_in = T[1 % M];
+                } else {
+                    // inner neighbour of the last node: previous node of this lane, or of the previous lane
+                    double up = UL, tp = T_prev_last;
+#pragma unroll
+                    for (int j = 1; j < M; j++) {
+                        up = (j == jl) ? U[j - 1] : up;
+                        tp = (j == jl) ? T[j - 1] : tp;
+                    }
+                    u_in = up;
+                    t_in = tp;
+                }
+                double Tc = back ? pick_last(T) : T[0];
+                const double dg = (0.0 - hs) - u_in;
+                const double nb = u_in * t_in;
+                double old_err = 99999.;
+                int count = 0;
+                for (;;) {
+                    const double qf = air_t * hs + rhs * (rad_t - Tc);
+                    const double q = ((back ? (nb + qf) : (qf + nb)) + sol) * -1.;
+                    const double x = q / dg;
+                    const double err = fabs(x - Tc);
+                    nm_passes++;
+                    if (err > old_err) break;                            // surface.rs:842-848
+                    if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
+                    Tc = (Tc + x) * 0.5;
+                    const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
+                    if (err < tol) break;
+                    old_err = err;
+                    count++;
+                }
+                if (!back) {
+                    T[0] = Tc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < M; j++) T[j] = (j == jl) ? Tc : T[j];
+                }
+                return;
+            }
         }
         const double tface = back ? pick_last(T) : T[0];
         h_out = hs;
@@ -773,24 +826,20 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         }
     }
 
-    if constexpr (NM) {
+    if constexpr (NM && PAL && !FUSED) {
         // ---- no-mass chunks (march_nomass, surface.rs:790-898), before the massive nodes march (surface.rs:950-965) ----
         // A chunk is one or two consecutive no-mass nodes between massive nodes and / or a face: a thin facing, two
         // light layers at a face (render on insulation), an insulation layer and an air gap inside a cavity wall. Its
-        // nodes sit in one lane; the class byte of its first node says so (bits 5-6: 1 or 2 nodes; per-node-array
-        // classes know one-node facings only). Every pass rebuilds the chunk's K and q as get_k_q does
+        // nodes sit in one lane; the class byte of its first node says so (bits 5-6: 1 or 2 nodes). Tiles whose only
+        // chunks are one-node facings (the common case, and all that per-node-array classes know) have solved them
+        // above; a tile marked kTileChunkyBit solves ALL its chunks here. Every pass rebuilds the chunk's K and q as get_k_q does
         // (discretization.rs:596-700: interior segments, then the front term, then the back term), solves K x = -q
         // (mut_n_diag_gaussian) and halves the distance, T <- (T + x) / 2, with the reference's exit rules.
         const double T_next_first = from_next_lane(T[0]);  // (wave-wide exchange, outside the divergent code)
         unsigned int starts = 0;                            // two bits per local node
-        if (nm_on && active) {
-            if constexpr (PAL) {
+        if (nm_on && chunky && active) {
 #pragma unroll
-                for (int j = 0; j < M; j++) starts |= (((cw[j >> 2] >> (8 * (j & 3))) >> 5) & 3u) << (2 * j);
-            } else {
-                if (is_first && Vat(0) == 0.0 && nn >= 2) starts |= 1u;
-                if (is_last && V_last() == 0.0 && nn >= 2 && !(is_first && jl == 0)) starts |= 1u << (2 * jl);
-            }
+            for (int j = 0; j < M; j++) starts |= (((cw[j >> 2] >> (8 * (j & 3))) >> 5) & 3u) << (2 * j);
         }
         while (__any(starts != 0)) {
             if (starts != 0) {
@@ -1111,7 +1160,7 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
         FastTile tile = tiles[w];
         const int kind = (tile.k >> kTileKindShift) & 3;
         const bool nm = (tile.k & kTileNmBit) != 0;
-        tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit));
+        tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit | kTileChunkyBit));
         switch (kind) {
         case 2:
             fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather,

@@ -43,6 +43,7 @@ struct FastTile {
     int16_t G;          // surfaces in this tile
 };
 constexpr int kTileMixedBit = 1 << 12;
+constexpr int kTileChunkyBit = 1 << 13;  // FastTile::k: the tile holds no-mass chunks other than one-node facings (kernels.hip)
 constexpr int kLaneLastBit = 1 << 12;
 constexpr int kLaneTableSlots = 128;  // node slots a mixed tile takes behind its M * Lk for the table (128 bytes used)
 

@@ -55,6 +55,7 @@ struct Category {
     int ncav;  // fast: gas cavities between massive nodes
     int pal;   // fast: the per-node constants fit a palette
     int m_ok;  // fast: blocking factors whose lanes hold every chunk whole (bit 0: 4, bit 1: 8, bit 2: 16 nodes per lane)
+    int chunky = 0;  // fast: has chunks other than one-node facings (inside the wall, or of two nodes)
 };
 inline int m_bit(int M) { return M == 4 ? 1 : (M == 8 ? 2 : 4); }
 
@@ -139,6 +140,7 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
     r.ncav = ncav;
     r.pal = pal;
     r.m_ok = m_ok;
+    r.chunky = (nm && !facings_only) ? 1 : 0;
     return r;
 }
 
@@ -291,7 +293,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     const std::vector<Placed> placed_streamed = placed;  // the plan without any cluster-resident march
     if (fuse && S > 0) {
         auto is_small = [&](int64_t s) { return cat[s].kind == kSmall || cat[s].kind == kSmallCav; };
-        auto fusable = [&](int64_t s) { return (cat[s].kind == 0 && cat[s].pal) || is_small(s); };
+        // (walls with no-mass chunks other than one-node facings are left to the streamed kernels)
+        auto fusable = [&](int64_t s) { return (cat[s].kind == 0 && cat[s].pal && !cat[s].chunky) || is_small(s); };
         auto zone_of_side = [&](int64_t s, int side) -> int32_t {
             const int kind = side ? d->back_kind[s] : d->front_kind[s];
             return kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
@@ -599,7 +602,9 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             FastTile t;
             t.node_base = node_cursor;
             t.surf_base = (int32_t)dcur;
-            t.k = (int16_t)((mixed_block ? (Lk | kTileMixedBit) : k) | (all_full ? 0x100 : 0));
+            bool any_chunky = false;
+            for (size_t q = pos; q < end; q++) any_chunky = any_chunky || cat[order[q]].chunky;
+            t.k = (int16_t)((mixed_block ? (Lk | kTileMixedBit) : k) | (all_full ? 0x100 : 0) | (any_chunky ? kTileChunkyBit : 0));
             t.G = (int16_t)(end - pos);
             const int tile_index = (int)fast_tiles[p0.cls].size();
             fast_tiles[p0.cls].push_back(t);
