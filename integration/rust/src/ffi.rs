@@ -47,9 +47,25 @@ extern "C" {
     // multi-GPU: one process per GPU, the library owns the RCCL communicator
     pub fn heat_comm_unique_id(id: *mut u8) -> c_int;
     pub fn heat_batch_comm_init(b: *mut HeatBatch, id: *const u8) -> c_int;
+    pub fn heat_comm_available() -> c_int;
+    // a model cut along its zone-connected clusters: no zone shared, no communicator needed
+    pub fn heat_partition(desc: *const HeatBatchDesc, n_ranks: i32, rank_of_surface: *mut i32,
+                          n_shared_zones: *mut i64) -> c_int;
+    pub fn heat_batch_create_shard(desc: *const HeatBatchDesc, opt: *const HeatBatchOptions,
+                                   rank_of_surface: *const i32, out: *mut *mut HeatBatch) -> c_int;
+    // which outputs travel back with every march (HEAT_OUT_*), and the rest on demand
+    pub fn heat_batch_march_ex(b: *mut HeatBatch, state: *mut f64, n_state: usize, weather: *const HeatWeather,
+                               n_sub: i32, zone_a0: *const f64, zone_b0: *const f64, what: i32) -> c_int;
+    pub fn heat_batch_download_outputs(b: *mut HeatBatch, state: *mut f64, n_state: usize, what: i32) -> c_int;
+    pub fn heat_batch_failed_surface(b: *const HeatBatch, index: *mut i64, kind: *mut i32) -> c_int;
     pub fn heat_batch_set_fusion(b: *mut HeatBatch, enabled: i32) -> c_int;
     pub fn heat_last_error() -> *const c_char;
 }
+
+pub const HEAT_OUT_NODE_TEMPERATURES: i32 = 1;
+pub const HEAT_OUT_SURFACE_SCALARS: i32 = 2;
+pub const HEAT_OUT_ZONE_TEMPERATURES: i32 = 4;
+pub const HEAT_OUT_ALL: i32 = 7;
 
 pub fn check(rc: c_int) -> Result<(), String> {
     if rc == 0 { Ok(()) } else {
