@@ -487,7 +487,7 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
 //                  streamed kernel runs all-massive and faced tiles through one variant)
 template <int M, int NM, int PAL, int CAV, int FUSED>
 __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter_index, bool nm_on, int lane, int wib,
-                                                double *s_pal, double *s_V, const FusedLds &fl, const FusedBlock &blk,
+                                                double *s_pal, double *s_V, double *s_pos, const FusedLds &fl, const FusedBlock &blk,
                                                 int blk_waves, int n_it, int step0, const NodeArrays &na,
                                                 const SideArrays &sd, const StepWeather *__restrict__ weather,
                                                 const double *__restrict__ zone_T, int *__restrict__ flags,
@@ -496,7 +496,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     constexpr bool kVinLds = FUSED && M == 16;
     double2 *const s_hT = fl.hT;
     double *const s_zT = fl.zT;
-    (void)s_hT; (void)s_zT; (void)s_V; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
+    (void)s_hT; (void)s_zT; (void)s_V; (void)s_pos; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
     const bool mixed = PAL && (tile.k & kTileMixedBit) != 0;  // (wave-uniform) surfaces of different lane counts
     // (wave-uniform) the tile holds no-mass chunks other than one-node facings: chunks inside the wall, of two nodes
     // (streamed variants only: the cluster-resident march leaves clusters with such walls to the streamed kernels — the
@@ -537,6 +537,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     const SideConst c_load = sd.sc[sidx];
     const SideDyn dy_load = sd.dyn[sidx];
     const int kind_n_mine = c_load.kind_n;
+    // streamed: a Space-facing side's place in its zone's contribution list waits in LDS for the end of the tile (in
+    // two registers across the RK stages it costs the 16-node variant its second wavefront per SIMD; fetched again
+    // from L2 at the end it is a dependent load in front of every tile's last store)
+    if constexpr (!FUSED) s_pos[threadIdx.x] = c_load.ambient;
     int my_lz = 0, b_lz = 0;
     double my_area = 0.0;
     if constexpr (FUSED) {
@@ -968,16 +972,12 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         o_hs = hs;
         o_flow = (face_t - my_air) * hs;
         if constexpr (!FUSED) {
-            // this side's share of its zone's heat balance, stored while the side record is still at hand
-            // (its position in the zone's list is fetched again, an L2 hit: held across the RK stages its two
-            // registers push the 16-node variant over the 256 of two wavefronts per SIMD)
+            // this side's share of its zone's heat balance (its place in the zone's list: from LDS, see above)
             if (active && (is_first || is_last) && (kind_n_mine & 3) == KIND_SPACE) {
-                int s2 = sidx;
-                asm volatile("" : "+v"(s2));
                 ZoneContrib z;
                 z.hs = hs;
                 z.t_face = face_t;
-                sd.zc[__double_as_longlong(sd.sc[s2].ambient)] = z;
+                sd.zc[__double_as_longlong(s_pos[threadIdx.x])] = z;
             }
         }
         if constexpr (FUSED) {
@@ -1062,6 +1062,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // balance is summed from, [2][kLanes] double2, and the zone temperatures (dynamic: > 64 KB for 8 waves).
     extern __shared__ double s_dyn[];
     __shared__ double s_pal_static[(PAL && !FUSED) ? kLanes * kPal : 2];
+    __shared__ double s_pos_static[FUSED ? 2 : kLanes];
     double *const s_pal = FUSED ? s_dyn : s_pal_static;
     // FUSED, after the palettes: with 16 nodes per lane V = dt/C of every node, [M][kLanes] (read where it is used:
     // held in registers over the march it would push that variant out of the register file); (hs * area, face temperature)
@@ -1114,7 +1115,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         }
         wave = blk.first_tile + wib;
     }
-    fast_tile_march<M, NM, PAL, CAV, FUSED>(tiles[wave], wave, true, lane, wib, s_pal, s_V, fl, blk, blk_waves, n_it, step0, na,
+    fast_tile_march<M, NM, PAL, CAV, FUSED>(tiles[wave], wave, true, lane, wib, s_pal, s_V, s_pos_static, fl, blk, blk_waves, n_it, step0, na,
                                             sd, weather, zone_T, flags, nomass_iters, fa);
 next_block:
     if constexpr (FUSED) {
@@ -1145,6 +1146,7 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
                   const double *__restrict__ zone_T, int *__restrict__ flags,
                   unsigned long long *__restrict__ nomass_iters) {
     __shared__ double s_pal[4 * kWave * kPal];
+    __shared__ double s_pos[4 * kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x >> 6;
     const int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
@@ -1163,15 +1165,15 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
         tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit | kTileChunkyBit));
         switch (kind) {
         case 2:
-            fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather,
+            fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
                                             zone_T, flags, nomass_iters, fa);
             break;
         case 1:
-            fast_tile_march<8, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
+            fast_tile_march<8, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
                                            flags, nomass_iters, fa);
             break;
         case 0:
-            fast_tile_march<4, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
+            fast_tile_march<4, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
                                            flags, nomass_iters, fa);
             break;
         default: {
