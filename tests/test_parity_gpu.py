@@ -305,6 +305,42 @@ def test_all_fourteen_energyplus_series_through_the_abi_full_length(oracle):
         assert abs(rm_ref - rm_got) < 1e-8 and rm_got < 0.5, (case, rm_ref, rm_got)
 
 
+@pytest.mark.parametrize("n_ranks,fusion", [(2, "plan"), (3, "plan"), (3, "stream"), (8, "plan")])
+def test_shards_of_the_cluster_partition_march_without_any_exchange(oracle, n_ranks, fusion):
+    """BASELINE config 4 as `bench.py --gpus N` runs it, here with every rank's batch on this one GPU: heat_partition
+    cuts the model along its zone-connected clusters (no zone shared), heat_batch_create_shard builds each rank's batch
+    from the WHOLE model's descriptor, every batch marches on its own (no communicator, no collective) and downloads
+    into the one caller state: its surfaces, and the zones it owns — faced zones and, of the zones nobody faces, every
+    n_ranks-th one, which still follow a0 / b0 (model.rs:410-423). The union equals the single-process oracle."""
+    from heat_amd import binding
+    md, st = mdl.clustered_massive(2400, Z=96, dt=45.0, seed=21)
+    for z in (5, 40, 77):   # zones nobody faces: their walls move to the pair's other zone
+        for key in ("front_zone", "back_zone"):
+            md[key] = np.where(md[key] == z, z ^ 1, md[key]).astype(np.int32)
+    w = mdl.weather_series(11, 45.0, wind_speed=2.5, wind_deg=310.0)
+    a0 = np.linspace(5., 80., 96)
+    b0 = np.linspace(0.2, 3., 96)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    ranks, n_shared = binding.partition(md, n_ranks)
+    assert n_shared == 0 and ranks.max() == n_ranks - 1
+    got = st.copy()
+    total_iters = 0
+    for r in range(n_ranks):
+        with HeatBatch(md, n_ranks=n_ranks, rank=r, rank_of_surface=ranks, no_fusion=(fusion == "stream"), use_graph=True) as b:
+            assert b.n_surfaces_in_batch == int((ranks == r).sum())
+            assert b.n_shared_zones == 0
+            b.upload_state(st)
+            b.march(got, w[:4], a0, b0)        # the caller-owned state: each rank writes its own slots only
+            b.march_resident(w[4:], a0, b0)
+            b.synchronize()
+            b.download_state(got)
+            total_iters += b.nomass_iterations()
+    assert total_iters == iters
+    assert_state_close(md, ref, got)
+
+
 @pytest.mark.parametrize("mode", ["planned", "streamed", "general"])
 def test_numerical_failure_names_the_surface(mode):
     """The reference's panic on a NaN convection coefficient names the values (surface.rs:704-707); the library
