@@ -425,7 +425,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_partial.zeros(2 * Z));
     b->partial_ptr = b->d_partial.p;
     HIP_TRY(b->d_state.zeros(p.n_state));
-    HIP_TRY(b->d_step.zeros(1));
+    HIP_TRY(b->d_step.zeros(2));  // [0] sub-timestep of the running march call, [1] its last one
     HIP_TRY(b->d_flags.zeros(4));  // [0] kinds OR-ed, [2..3] first failing surface / zone (report_failure, kernels.hip)
     HIP_TRY(hipMemset(b->d_flags.p + 2, 0xff, 2 * sizeof(int)));
     b->h_orig_of = p.orig_of;
@@ -1042,7 +1042,7 @@ int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n
     if (!b->ev_staged) HIP_TRY(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->ev_staged, b->stream));
     b->staged = true;
-    launch_set_step(b->d_step.p, 0, b->stream);
+    launch_set_step(b->d_step.p, 0, n_sub - 1, b->stream);
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
 }

@@ -344,8 +344,10 @@ __device__ __forceinline__ unsigned int small_tile_march(int64_t node_base, int 
     return iters;
 }
 
+// (two wavefronts per SIMD asked for: the cavity variant sits at 260 registers otherwise and runs 100 000 windows in
+// two rounds of 1 024 wavefronts instead of one of 1 563)
 template <int CAV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base,
                  SideArrays sd, const CavityDev *__restrict__ cavs,
                  const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
@@ -482,6 +484,8 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
 
 // One tile of a fast class: n_it sub-timesteps (one, unless FUSED) of its surfaces. The body of k_surfaces_fast and
 // of the fast-path cases of k_surfaces_stream.
+//   write_out      streamed: hs and the heat flows (model.rs:154-169) are observable after the LAST sub-timestep of a
+//                  march call only — the launches before it leave those 32 bytes per surface unwritten
 //   counter_index  slot of the tile in `nomass_iters` (NM)
 //   nm_on          NM variants: whether this tile holds walls with no-mass facings at all (wave-uniform; the unified
 //                  streamed kernel runs all-massive and faced tiles through one variant)
@@ -491,7 +495,8 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                                                 int blk_waves, int n_it, int step0, const NodeArrays &na,
                                                 const SideArrays &sd, const StepWeather *__restrict__ weather,
                                                 const double *__restrict__ zone_T, int *__restrict__ flags,
-                                                unsigned long long *__restrict__ nomass_iters, const FusedArgs &fa) {
+                                                unsigned long long *__restrict__ nomass_iters, const FusedArgs &fa,
+                                                bool write_out = true) {
     constexpr int kLanes = (FUSED ? FUSED : 4) * kWave;
     constexpr bool kVinLds = FUSED && M == 16;
     double2 *const s_hT = fl.hT;
@@ -1011,13 +1016,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         }
         if (threadIdx.x < blk.n_zones) fa.zone_T[fa.zones[blk.first_zone + threadIdx.x]] = s_zT[threadIdx.x];
     }
-    if (active && (is_first || is_last)) {
+    if (write_out && active && (is_first || is_last)) {
         SideOut o;
         o.hs = o_hs;
         o.flow = o_flow;
         sd.out[sidx] = o;
     }
-    if (single && active) {
+    if (write_out && single && active) {
         SideOut o;
         o.hs = o2_hs;
         o.flow = o2_flow;
@@ -1088,6 +1093,8 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     __shared__ int s_next_block;
     const int n_it = FUSED ? fa.n_sub : 1;
     const int step0 = FUSED ? 0 : ((step_fixed >= 0) ? step_fixed : *step_ptr);
+    // (step_ptr[1]: index of the last sub-timestep of the running march call; a caller that steps by hand gets every output)
+    const bool write_out = FUSED || step_fixed >= 0 || step0 == step_ptr[1];
     // Streaming (FUSED = 0), persistent waves: each walks the tile list with a grid stride, so the write-back of
     // one tile (a wave cannot retire before its stores are acknowledged) overlaps the loads of the next.
     // FUSED: one pass per FusedBlock; with a work queue (sharded batches, fa.queue) the workgroup takes further ones.
@@ -1116,7 +1123,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         wave = blk.first_tile + wib;
     }
     fast_tile_march<M, NM, PAL, CAV, FUSED>(tiles[wave], wave, true, lane, wib, s_pal, s_V, s_pos_static, fl, blk, blk_waves, n_it, step0, na,
-                                            sd, weather, zone_T, flags, nomass_iters, fa);
+                                            sd, weather, zone_T, flags, nomass_iters, fa, write_out);
 next_block:
     if constexpr (FUSED) {
         if (fa.queue == nullptr) break;
@@ -1152,6 +1159,7 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
     const int wave0 = blockIdx.x * (blockDim.x >> 6) + wib;
     const int n_waves = gridDim.x * (blockDim.x >> 6);
     const int step0 = (step_fixed >= 0) ? step_fixed : *step_ptr;
+    const bool write_out = step_fixed >= 0 || step0 == step_ptr[1];
     const FusedLds fl{};
     const FusedBlock blk{0, 0, 0, 0, 0, 0};
     const FusedArgs fa{};
@@ -1166,15 +1174,15 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
         switch (kind) {
         case 2:
             fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
-                                            zone_T, flags, nomass_iters, fa);
+                                            zone_T, flags, nomass_iters, fa, write_out);
             break;
         case 1:
             fast_tile_march<8, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
-                                           flags, nomass_iters, fa);
+                                           flags, nomass_iters, fa, write_out);
             break;
         case 0:
             fast_tile_march<4, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
-                                           flags, nomass_iters, fa);
+                                           flags, nomass_iters, fa, write_out);
             break;
         default: {
             unsigned int tot = small_tile_march<0>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, weather[step0],
@@ -1672,7 +1680,10 @@ k_outputs_compact(int n_surf, int n_zones, const SideOut *__restrict__ out, cons
     if (i < n_zones) dst[4 * (int64_t)n_surf + i] = zone_T[i];
 }
 
-__global__ void k_set_step(int *step_ptr, int v) { *step_ptr = v; }
+__global__ void k_set_step(int *step_ptr, int v, int last) {
+    step_ptr[0] = v;
+    step_ptr[1] = last;
+}
 
 // ---------------------------------------------------------------------------
 // Launch wrappers (host).
@@ -1891,8 +1902,8 @@ void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const i
     hipLaunchKernelGGL(k_outputs_compact, dim3((n + 255) / 256), dim3(256), 0, st, n_surf, n_zones, out, orig_of, zone_T, dst);
 }
 
-void launch_set_step(int *step_ptr, int v, hipStream_t st) {
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, step_ptr, v);
+void launch_set_step(int *step_ptr, int v, int last, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, step_ptr, v, last);
 }
 
 }  // namespace heat

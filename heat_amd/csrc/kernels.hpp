@@ -55,6 +55,6 @@ void launch_inputs_compact(int n_surf, int n_zones, const double *in, const doub
                            hipStream_t st);
 void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const int32_t *orig_of, const double *zone_T,
                             double *dst, hipStream_t st);
-void launch_set_step(int *step_ptr, int v, hipStream_t st);
+void launch_set_step(int *step_ptr, int v, int last, hipStream_t st);
 
 }  // namespace heat
