@@ -272,11 +272,17 @@ def main():
         import torch
         import torch.distributed as dist
         from heat_amd.sharded import ShardedMarch, partition_model
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # (HEAT_AMD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU, where
+            # RCCL refuses a second rank on the same device; only barriers and the timing reduction go through it)
+            backend = os.environ.get("HEAT_AMD_BENCH_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
         forced = None
         if args.force_shared_zones > 0:
             forced = np.unique(np.linspace(0, int(md["n_zones"]) - 1, args.force_shared_zones).astype(np.int32))
@@ -284,7 +290,8 @@ def main():
         if not weak:
             # every rank cuts the same model the same way (host-only, deterministic): whole clusters per rank
             ranks, n_shared_partition = partition_model(md, world)
-        sm = ShardedMarch(md, rank, world, device_index=local_rank, collective=args.collective, force_shared=forced,
+        sm = ShardedMarch(md, rank, world, device_index=local_rank % max(torch.cuda.device_count(), 1),
+                          collective=args.collective, force_shared=forced,
                           rank_of_surface=ranks, n_shared_in_partition=n_shared_partition,
                           nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=args.no_fusion,
                           use_graph=True)
@@ -322,7 +329,7 @@ def main():
     if sharded:
         import torch
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
