@@ -737,6 +737,20 @@ hipEvent_t next_event(heat_batch *b) {
     return b->ev_pool[b->ev_used++];
 }
 
+// A march call that forks work onto the fused stream, or swaps the partials buffer, must leave the batch consistent
+// on EVERY return path: an early error return would otherwise leave the side stream unjoined (a later download that
+// synchronises only the batch's stream would race with the still-running launch) or the partials pointer swapped.
+struct MarchGuard {
+    heat_batch *b;
+    double *saved_partial;
+    bool forked = false, joined = false;
+    explicit MarchGuard(heat_batch *b_) : b(b_), saved_partial(b_->partial_ptr) {}
+    ~MarchGuard() {
+        b->partial_ptr = saved_partial;
+        if (forked && !joined && b->fused_stream) (void)hipStreamSynchronize(b->fused_stream);  // error path: wait it out
+    }
+};
+
 }  // namespace
 
 // ===========================================================================
@@ -1306,7 +1320,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         // in rank order (identical bits on every rank).
         Rccl *r = rccl();
         if (!r) return fail(HEAT_E_COMM, "RCCL is not loaded");
-        double *saved_partial = b->partial_ptr;
+        MarchGuard guard(b);
         b->partial_ptr = b->d_partial.p;
         // The clusters that own no shared zone march beside the exchange loop, in one launch per class on a side
         // stream: only the few surfaces around the shared zones go through kernel -> all-gather -> kernel every
@@ -1317,6 +1331,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
             hipStream_t fs = b->fused_stream;
             HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
             HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
+            guard.forked = true;
             hipEvent_t f0 = nullptr, f1 = nullptr;
             if (b->timing) {
                 f0 = next_event(b); f1 = next_event(b);
@@ -1352,8 +1367,10 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
                 b->ev_triples.push_back({e0, e1, e2});
             }
         }
-        if (fused) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fused, 0));
-        b->partial_ptr = saved_partial;
+        if (fused) {
+            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fused, 0));
+            guard.joined = true;
+        }
         HIP_TRY(hipGetLastError());
         return HEAT_OK;
     }
@@ -1368,12 +1385,14 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         streamed = streamed || b->n_gen_tiles > 0 || b->n_stream_zones > 0;
     }
     hipStream_t fs = b->stream;
+    MarchGuard guard(b);
     if (fused) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (streamed && b->fused_stream != nullptr) {
             fs = b->fused_stream;
             HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
             HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
+            guard.forked = true;
         }
         if (b->timing) {
             e0 = next_event(b); e1 = next_event(b);
@@ -1423,6 +1442,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     if (fused && fs != b->stream) {
         HIP_TRY(hipEventRecord(b->ev_fused, fs));
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_fused, 0));
+        guard.joined = true;
     }
     HIP_TRY(hipGetLastError());
     return HEAT_OK;

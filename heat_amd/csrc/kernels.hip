@@ -374,7 +374,13 @@ struct FusedLds {
     unsigned short *slots;
 };
 
-// The block's zone data -> LDS (every wavefront of the block takes part; ends with a barrier).
+// Barriers a wavefront of a fused workgroup passes: one at the end of fused_block_init, two per sub-timestep in
+// fused_zone_phase. A wavefront without a tile that stays for the work queue keeps step with exactly these counts
+// (k_surfaces_fast); a wavefront that leaves instead (no queue) drops out of the barrier's count on gfx9.
+constexpr int kFusedBarriersAtInit = 1;
+constexpr int kFusedBarriersPerSubstep = 2;
+
+// The block's zone data -> LDS (every wavefront of the block takes part; ends with kFusedBarriersAtInit barrier).
 __device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int n_threads) {
     const int e_first = fa.zone_eoff[blk.first_zone];
     if ((int)threadIdx.x <= blk.n_zones) l.zoff[threadIdx.x] = fa.zone_eoff[blk.first_zone + threadIdx.x] - e_first;
@@ -1106,11 +1112,11 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             // no tile for this wavefront. One FusedBlock per workgroup: done (a finished wave does not take part in
             // s_barrier). With the queue it has to stay for the next block, and keeps step with the barriers.
             if (fa.queue == nullptr) return;
-            __syncthreads();
-            for (int it = 0; it < fa.n_sub; it++) {
-                __syncthreads();
-                __syncthreads();
-            }
+            // kFusedBarriersAtInit + kFusedBarriersPerSubstep * n_sub: the same count as a working wavefront passes
+            // (fused_block_init ends with one barrier, fused_zone_phase brackets the zone sums with two)
+            for (int q = 0; q < kFusedBarriersAtInit; q++) __syncthreads();
+            for (int it = 0; it < fa.n_sub; it++)
+                for (int q = 0; q < kFusedBarriersPerSubstep; q++) __syncthreads();
             goto next_block;
         }
         if constexpr (SMALL) {
