@@ -834,6 +834,32 @@ def test_config3_at_full_size_fast_kernels_equal_the_catch_all_kernel():
     assert np.allclose(res[0][0], res[1][0], rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize("config", ["headline", "3"])
+def test_full_size_against_the_whole_oracle(oracle, config):
+    """The oracle, threaded over the surfaces on the box's host cores (the reference's disabled rayon path,
+    model.rs:113-116), marches the FULL BASELINE sizes in seconds: 1 000 000 x 32 (cluster-resident march) and the
+    1 000 000 ragged mixed surfaces of config 3 (one streamed launch per sub-timestep) are compared slot by slot."""
+    if config == "headline":
+        md, st = mdl.uniform_massive(1_000_000, 32, Z=10_000, dt=45.0)
+        n_sub = 10
+    else:
+        md, st = mdl.ragged_mixed(1_000_000, dt=45.0)
+        n_sub = 8
+    w = mdl.weather_series(n_sub, 45.0, wind_speed=3.2, wind_deg=230.0)
+    rng = np.random.default_rng(77)
+    a0 = rng.uniform(0., 200., int(md["n_zones"]))
+    b0 = rng.uniform(0., 5., int(md["n_zones"]))
+    ref = st.copy()
+    rc, _ = oracle.OracleModel(md).march(ref, w, a0, b0, threads=16)
+    assert rc == 0
+    got = st.copy()
+    with HeatBatch(md, use_graph=True) as b:
+        assert (b.n_fused_surfaces > 0) == (config == "headline")
+        b.upload_state(got)
+        b.march(got, w, a0, b0)
+    assert_state_close(md, ref, got)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_planner_stress_random_zone_graphs(oracle, seed):
     """Random small models — walls, facings, windows, partitions, walls between random pairs of zones, zones nobody faces,
