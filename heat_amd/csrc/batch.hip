@@ -1388,7 +1388,10 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     MarchGuard guard(b);
     if (fused) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (streamed && b->fused_stream != nullptr) {
+        // A small batch runs its streamed remainder beside the fused launch (both are latency-bound and leave the chip
+        // mostly empty); a large one runs them one after the other on the batch's stream: side by side the streamed
+        // kernels wait for wavefront slots the fused launch holds for its whole duration.
+        if (streamed && b->fused_stream != nullptr && b->n_surf <= 8192) {
             fs = b->fused_stream;
             HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
             HIP_TRY(hipStreamWaitEvent(fs, b->ev_fork, 0));
@@ -1399,7 +1402,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
             if (!e0 || !e1) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(e0, fs));
         }
-        rc = enqueue_fused(b, n_sub, fs, streamed);
+        rc = enqueue_fused(b, n_sub, fs, streamed && fs != b->stream);
         if (rc) return rc;
         if (b->timing) {
             HIP_TRY(hipEventRecord(e1, fs));
@@ -1551,7 +1554,8 @@ int heat_batch_get_timing(heat_batch *b, double *surf_us, double *substep_us, in
     // With a cluster-resident march the surface kernel of a sub-timestep is 1/n_sub of the fused launch (the
     // streamed remainder, if any, runs beside it on another stream).
     if (surf_us) *surf_us = n_fused_steps ? fused_us : stream_surf;
-    if (substep_us) *substep_us = n_fused_steps ? std::max(fused_us, stream_all) : stream_all;
+    // (a large batch runs its streamed remainder after the fused launch, a small one beside it)
+    if (substep_us) *substep_us = n_fused_steps ? (b->n_surf > 8192 ? fused_us + stream_all : std::max(fused_us, stream_all)) : stream_all;
     if (n_samples) *n_samples = n_fused_steps ? n_fused_steps : (int64_t)n;
     b->ev_used = 0;
     b->ev_triples.clear();

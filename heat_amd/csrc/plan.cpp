@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -501,10 +502,13 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         }
     }
     if (fuse && !fuse_always && !blocks.empty()) {
-        // Fusing part of a batch does not pay: the streamed remainder still pays its launches and latencies every
-        // sub-timestep, and the two kinds of kernels share the chip badly (measured: 2 000 clustered walls with 733
-        // of them fused 89 us per sub-timestep against 64 all streamed; 1 M clustered walls with 205 000 fused 260
-        // against 222). A small batch is fused only as a whole, a large one when at least nine tenths of its nodes are.
+        // A SMALL batch (bound by launches, not by throughput) is fused only as a whole: a streamed remainder would
+        // still pay its launches every sub-timestep (2 000 clustered walls with 733 of them fused: 89 us per
+        // sub-timestep against 64 all streamed). A large batch fuses the clusters that gain and streams the rest
+        // AFTER them in the same march call, on the same stream (heat_batch_march_resident): the two kinds of kernels
+        // never share the chip — side by side they did badly (1 M clustered walls with 205 000 fused: 260 against 222
+        // all streamed) —, so every fused cluster keeps its gain; below a tenth of the batch's nodes the fused
+        // launch's own ramp and tail are not worth it.
         double fused_nodes = 0.0, all_nodes = 0.0;
         bool remainder = false;
         for (int64_t s = 0; s < S; s++) {
@@ -512,9 +516,14 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             if (placed[s].blk >= 0) fused_nodes += placed[s].n;
             else remainder = true;
         }
-        if (S <= 8192 ? remainder : fused_nodes < 0.9 * all_nodes) {
+        static const double min_share = getenv("HEAT_AMD_FUSE_MIN_SHARE") ? atof(getenv("HEAT_AMD_FUSE_MIN_SHARE")) : 0.1;
+        if (S <= 8192 ? remainder : fused_nodes < min_share * all_nodes) {
             placed = placed_streamed;
             blocks.clear();
+        } else if (remainder) {
+            // the streamed remainder keeps the blocking factors of the all-streamed plan
+            for (int64_t s = 0; s < S; s++)
+                if (placed[s].blk < 0) placed[s] = placed_streamed[s];
         }
     }
     for (int64_t s = 0; s < S; s++) {
