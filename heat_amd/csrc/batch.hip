@@ -266,6 +266,10 @@ struct heat_batch {
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
     std::vector<std::pair<int64_t, int64_t>> out_chunks;  // surface ranges of the node part, a staging half each
     HostPool *pool = nullptr;
+    // Runs of the state in which EVERY slot is an output of this path or an input it was just handed (the reference's
+    // layout: one run over all surface blocks, surface_trait.rs:223-378). heat_batch_march copies them from the state
+    // mirror straight into the caller's array — no staging, no host scatter. Empty: the layout is not of that kind.
+    std::vector<std::pair<int64_t, int64_t>> direct_runs;
 
     // host copies for download (original surface order)
     std::vector<int64_t> h_first_slot, h_node_count, h_out_slots[4], h_zone_slot_h;
@@ -466,6 +470,28 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         }
         HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
         for (auto &e : b->ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        {   // direct runs (see heat_batch::direct_runs)
+            static const bool no_direct = getenv("HEAT_AMD_NO_DIRECT_DOWNLOAD") != nullptr;
+            std::vector<uint8_t> mask((size_t)p.n_state, 0);
+            const int64_t *sc[8] = {d->hs_front_slot, d->hs_back_slot, d->flow_front_slot, d->flow_back_slot,
+                                    d->solar_front_slot, d->solar_back_slot, d->ir_front_slot, d->ir_back_slot};
+            for (int64_t s = 0; s < S; s++) {
+                const int64_t n = d->node_offset[s + 1] - d->node_offset[s];
+                memset(&mask[d->first_node_slot[s]], 1, (size_t)n);
+                for (int a = 0; a < 8; a++) mask[sc[a][s]] = 1;
+            }
+            int64_t covered = 0, wanted = 0;
+            for (int64_t i = 0; i < p.n_state;) {
+                if (!mask[i]) { i++; continue; }
+                int64_t e = i;
+                while (e < p.n_state && mask[e]) e++;
+                wanted += e - i;
+                if (e - i >= 65536) { b->direct_runs.push_back({i, e}); covered += e - i; }
+                i = e;
+            }
+            // all of the surfaces' slots in a few long runs, or nothing (the staged path serves any layout)
+            if (no_direct || covered != wanted || b->direct_runs.size() > 64) b->direct_runs.clear();
+        }
         static const int n_env = getenv("HEAT_AMD_HOST_THREADS") ? atoi(getenv("HEAT_AMD_HOST_THREADS")) : 0;
         const int hw = (int)std::thread::hardware_concurrency();
         b->pool = new HostPool(n_env > 0 ? n_env : std::max(1, std::min(hw > 0 ? hw : 8, S > 20000 ? 16 : 1)));
@@ -931,7 +957,8 @@ int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state)
     for (int64_t z = 0; z < Z; z++) pin[4 * S + z] = state[b->h_zone_slot_h[z]];
     if (4 * S + Z > 0)
         HIP_TRY(hipMemcpyAsync(b->d_compact.p, pin, (size_t)(4 * S + Z) * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    launch_inputs_compact((int)S, (int)Z, b->d_compact.p, b->d_side_alpha.p, b->d_side_dyn.p, b->d_zone_T.p, b->stream);
+    launch_inputs_compact((int)S, (int)Z, b->d_compact.p, b->d_side_alpha.p, b->d_side_dyn.p, b->d_zone_T.p, b->sl,
+                          b->direct_runs.empty() ? nullptr : b->d_state.p, b->stream);
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
 }
@@ -943,14 +970,43 @@ int heat_batch_download_state(heat_batch *b, double *state, size_t n_state) {
 // The outputs of this path into the caller's state: gathered on the device into a compact buffer in the caller's
 // surface order, copied through two pinned staging halves (the copy of one piece runs while the thread pool
 // scatters the piece before it), only the slots the path owns are written.
+static int download_impl(heat_batch *b, double *state, size_t n_state, int32_t what, bool inputs_fresh);
+
 int heat_batch_download_outputs(heat_batch *b, double *state, size_t n_state, int32_t what) {
+    return download_impl(b, state, n_state, what, false);
+}
+
+// inputs_fresh: the irradiance slots of `state` were uploaded from this very array in the same call (heat_batch_march):
+// the mirror then equals the caller's state on every slot of the direct runs that is not an output, and whole runs can
+// be copied back.
+static int download_impl(heat_batch *b, double *state, size_t n_state, int32_t what, bool inputs_fresh) {
     if (!b || !state) return fail(HEAT_E_INVALID_ARG, "NULL argument");
     if ((int64_t)n_state != b->n_state) return fail(HEAT_E_SIZE, "n_state %zu, batch was created for %lld", n_state, (long long)b->n_state);
     int rc = select_device(b);
     if (rc) return rc;
     const int64_t S = b->n_surf, Z = b->n_zones, N = b->n_nodes;
-    const bool nodes = (what & HEAT_OUT_NODE_TEMPERATURES) != 0;
-    const bool scalars = (what & (HEAT_OUT_SURFACE_SCALARS | HEAT_OUT_ZONE_TEMPERATURES)) != 0;
+    bool nodes = (what & HEAT_OUT_NODE_TEMPERATURES) != 0;
+    bool scalars = (what & (HEAT_OUT_SURFACE_SCALARS | HEAT_OUT_ZONE_TEMPERATURES)) != 0;
+    if (nodes && (what & HEAT_OUT_SURFACE_SCALARS) && inputs_fresh && !b->direct_runs.empty()) {
+        // Direct: node temperatures, hs and heat flows go into the mirror; its runs — outputs and the inputs this call
+        // uploaded, nothing else — are copied straight into the caller's array (pageable or not: 56 GB/s either way on
+        // this platform, tools/pcie_bw.py). The zones follow through the staged path below.
+        for (int c = 0; c < kNumFast; c++)
+            launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
+                              b->d_first_slot.p, b->d_state.p, 1, b->d_cls.p, b->stream);
+        launch_nodes_general(b->d_gen_tiles.p, b->n_gen_tiles, b->d_T.p, b->d_meta.p, b->d_first_slot.p, b->d_state.p, 1,
+                             b->stream);
+        launch_surf_scalars((int)S, b->sl, b->d_side_dyn.p, b->d_side_out.p, b->d_side_alpha.p, b->d_state.p, 1, 2, b->stream);
+        HIP_TRY(hipGetLastError());
+        for (auto &r : b->direct_runs)
+            HIP_TRY(hipMemcpyAsync(state + r.first, b->d_state.p + r.first, (size_t)(r.second - r.first) * sizeof(double),
+                                   hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        nodes = false;
+        what &= ~(HEAT_OUT_NODE_TEMPERATURES | HEAT_OUT_SURFACE_SCALARS);
+        scalars = (what & HEAT_OUT_ZONE_TEMPERATURES) != 0;
+        if (!scalars) return HEAT_OK;
+    }
     if (nodes) {
         for (int c = 0; c < kNumFast; c++)
             launch_nodes_fast(kFastM[c], b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->d_T.p, b->d_meta.p,
@@ -966,7 +1022,9 @@ int heat_batch_download_outputs(heat_batch *b, double *state, size_t n_state, in
     // the scalar part first (one piece), then the node pieces; piece i uses staging half i % 2
     struct Piece { int64_t off, count, s0, s1; bool is_nodes; };
     std::vector<Piece> pieces;
-    if (scalars) pieces.push_back({N, 4 * S + Z, 0, S, false});
+    // (zones alone: only the tail of the scalar part travels)
+    const int64_t sc_off = (what & HEAT_OUT_SURFACE_SCALARS) ? 0 : 4 * S;
+    if (scalars) pieces.push_back({N + sc_off, 4 * S + Z - sc_off, 0, S, false});
     if (nodes)
         for (auto &ch : b->out_chunks)
             pieces.push_back({b->h_node_off[ch.first], b->h_node_off[ch.second] - b->h_node_off[ch.first], ch.first, ch.second, true});
@@ -1006,7 +1064,7 @@ int heat_batch_download_outputs(heat_batch *b, double *state, size_t n_state, in
                 });
             if (what & HEAT_OUT_ZONE_TEMPERATURES)
                 for (int64_t z = 0; z < Z; z++)
-                    if (b->h_owned[z]) state[b->h_zone_slot_h[z]] = src[4 * S + z];
+                    if (b->h_owned[z]) state[b->h_zone_slot_h[z]] = src[4 * S - sc_off + z];
         }
         if (!overlap && i + 1 < pieces.size()) HIP_TRY(issue(i + 1));
     }
@@ -1496,7 +1554,7 @@ int heat_batch_march_ex(heat_batch *b, double *state, size_t n_state, const heat
     if (rc) return rc;
     rc = heat_batch_synchronize(b);
     if (rc) return rc;
-    return heat_batch_download_outputs(b, state, n_state, what);
+    return download_impl(b, state, n_state, what, true);
 }
 
 int64_t heat_batch_nomass_iterations(heat_batch *b) {

@@ -1652,10 +1652,18 @@ k_zone_scalars(int n_zones, const int64_t *__restrict__ zone_slot, double *__res
 // the host, one pinned copy) — the clamps and conversions of k_surf_scalars, without the state mirror.
 __global__ void __launch_bounds__(256)
 k_inputs_compact(int n_surf, int n_zones, const double *__restrict__ in, const double *__restrict__ side_alpha,
-                 SideDyn *__restrict__ dyn, double *__restrict__ zone_T) {
+                 SideDyn *__restrict__ dyn, double *__restrict__ zone_T, SlotArrays sl, double *__restrict__ mirror) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int S = n_surf;
     if (i < S) {
+        if (mirror != nullptr) {
+            // the state mirror keeps the caller's raw values of these slots: a download that copies whole runs of the
+            // mirror into the caller's state (heat_batch_march) hands them back unchanged
+            mirror[sl.solar_f[i]] = in[i];
+            mirror[sl.solar_b[i]] = in[S + i];
+            mirror[sl.ir_f[i]] = in[2 * (int64_t)S + i];
+            mirror[sl.ir_b[i]] = in[3 * (int64_t)S + i];
+        }
         double sf = in[i];
         if (sf != sf || sf < 0.0) sf = 0.0;  // surface.rs:916-923
         double sb = in[S + i];
@@ -1895,10 +1903,11 @@ void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, 
 }
 
 void launch_inputs_compact(int n_surf, int n_zones, const double *in, const double *side_alpha, SideDyn *dyn, double *zone_T,
-                           hipStream_t st) {
+                           const SlotArrays &sl, double *mirror, hipStream_t st) {
     const int n = std::max(n_surf, n_zones);
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_inputs_compact, dim3((n + 255) / 256), dim3(256), 0, st, n_surf, n_zones, in, side_alpha, dyn, zone_T);
+    hipLaunchKernelGGL(k_inputs_compact, dim3((n + 255) / 256), dim3(256), 0, st, n_surf, n_zones, in, side_alpha, dyn, zone_T,
+                       sl, mirror);
 }
 
 void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const int32_t *orig_of, const double *zone_T,

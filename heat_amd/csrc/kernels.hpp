@@ -52,7 +52,7 @@ void launch_surf_scalars(int n_surf, const SlotArrays &sl, SideDyn *dyn, SideOut
 void launch_zone_scalars(int n_zones, const int64_t *zone_slot, double *zone_T, double *state, int to_state,
                          hipStream_t st);
 void launch_inputs_compact(int n_surf, int n_zones, const double *in, const double *side_alpha, SideDyn *dyn, double *zone_T,
-                           hipStream_t st);
+                           const SlotArrays &sl, double *mirror, hipStream_t st);
 void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const int32_t *orig_of, const double *zone_T,
                             double *dst, hipStream_t st);
 void launch_set_step(int *step_ptr, int v, int last, hipStream_t st);
