@@ -213,7 +213,7 @@ struct heat_batch {
     DevBuf<int32_t> d_cav_idx;
     DevBuf<int32_t> d_cavref;  // CAV fast classes: 4 ints per device surface
     DevBuf<uint8_t> d_cls;   // palette class bytes (PAL fast classes)
-    DevBuf<double> d_pal;    // palettes, kPal doubles per device surface
+    DevBuf<double> d_pal;    // palettes, na.pal_stride doubles per device surface
     DevBuf<CavityDev> d_cavs;
 
     DevBuf<int32_t> d_meta;        // node count per device surface (upload/download kernels)
@@ -510,6 +510,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     NodeArrays &na = b->na;
     na.T = b->d_T.p; na.V = b->d_V.p; na.U = b->d_U.p;
     na.cls = b->d_cls.p; na.pal = b->d_pal.p;
+    na.pal_stride = p.pal_stride;
+    na.pal_ubase = p.pal_ubase;
     na.cavref = b->d_cavref.p; na.cavs = b->d_cavs.p;
     na.alpha_f = b->d_alpha_f.p; na.alpha_b = b->d_alpha_b.p; na.cav = b->d_cav_idx.p; na.mass = b->d_mass.p;
     SlotArrays &sl = b->sl;
@@ -733,7 +735,7 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
             if (beside_exchange) {
                 const int fw = (g2 & 1) ? 8 : 4;
                 static const int room_env = getenv("HEAT_AMD_FUSED_ROOM") ? atoi(getenv("HEAT_AMD_FUSED_ROOM")) : 0;  // tests
-                const int room = room_env > 0 ? room_env : n_cu * fused_blocks_per_cu(kFastM[c], kFastCAV[c], g2 >> 1, fw);
+                const int room = room_env > 0 ? room_env : n_cu * fused_blocks_per_cu(kFastM[c], kFastCAV[c], g2 >> 1, fw, b->na.pal_stride);
                 const int reserve = reserve_env >= 0 ? reserve_env
                                                      : std::min(room / 2, std::max(fw == 4 ? 16 : 8, (int)(room * streamed_share)));
                 if (nb > room - reserve) {

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "device_math.hpp"
@@ -566,11 +567,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     unsigned int cw[M / 4];  // PAL: the lane's class bytes, four per word
     (void)cw;
     if constexpr (PAL) {
-        double *sp = s_pal + wib * (kWave * kPal);
-        {   // the palettes of this tile's surfaces: G * kPal contiguous doubles -> LDS
-            const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * kPal);
+        const int pstride = na.pal_stride;  // doubles per palette (layout.hpp)
+        const int ubase = na.pal_ubase;
+        double *sp = s_pal + wib * (kWave * pstride);
+        {   // the palettes of this tile's surfaces: G * pstride contiguous doubles -> LDS
+            const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * pstride);
             double2 *sp2 = reinterpret_cast<double2 *>(sp);
-            const int n2 = G * (kPal / 2);
+            const int n2 = G * (pstride / 2);
             for (int i = lane; i < n2; i += kWave) sp2[i] = gp[i];
         }
         {
@@ -594,12 +597,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         }
         __builtin_amdgcn_wave_barrier();  // LDS writes above are ordered before the reads below (same wave)
         {
-            const double *mp = sp + g * kPal;
+            const double *mp = sp + g * pstride;
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 const unsigned int cbj = (cw[j >> 2] >> (8 * (j & 3))) & 0xff;
-                V[j] = mp[cbj & (kPalV - 1)];
-                U[j] = mp[kPalV + ((cbj >> 3) & (kPalU - 1))];  // (bits 5-6: no-mass chunk marks, see below)
+                const unsigned int vi = cbj & (kPalV - 1);
+                V[j] = mp[vi >= kPalVMark1 ? 0u : vi];  // (14, 15: no-mass chunk marks, see below; entry 0 is 0.0)
+                U[j] = mp[ubase + ((cbj >> kPalUShift) & (kPalU - 1))];
             }
         }
         if constexpr (kVinLds) {
@@ -845,7 +849,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         // ---- no-mass chunks (march_nomass, surface.rs:790-898), before the massive nodes march (surface.rs:950-965) ----
         // A chunk is one or two consecutive no-mass nodes between massive nodes and / or a face: a thin facing, two
         // light layers at a face (render on insulation), an insulation layer and an air gap inside a cavity wall. Its
-        // nodes sit in one lane; the class byte of its first node says so (bits 5-6: 1 or 2 nodes). Tiles whose only
+        // nodes sit in one lane; the class byte of its first node says so (V index 14 or 15: 1 or 2 nodes). Tiles whose only
         // chunks are one-node facings (the common case, and all that per-node-array classes know) have solved them
         // above; a tile marked kTileChunkyBit solves ALL its chunks here. Every pass rebuilds the chunk's K and q as get_k_q does
         // (discretization.rs:596-700: interior segments, then the front term, then the back term), solves K x = -q
@@ -854,7 +858,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         unsigned int starts = 0;                            // two bits per local node
         if (nm_on && chunky && active) {
 #pragma unroll
-            for (int j = 0; j < M; j++) starts |= (((cw[j >> 2] >> (8 * (j & 3))) >> 5) & 3u) << (2 * j);
+            for (int j = 0; j < M; j++) {
+                const unsigned int vi = (cw[j >> 2] >> (8 * (j & 3))) & (kPalV - 1);
+                starts |= (vi >= kPalVMark1 ? vi - (kPalVMark1 - 1) : 0u) << (2 * j);
+            }
         }
         while (__any(starts != 0)) {
             if (starts != 0) {
@@ -1072,15 +1079,14 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // LDS: the palettes of the block's tiles; FUSED adds the per-side (hs, face temperature) pairs the zone
     // balance is summed from, [2][kLanes] double2, and the zone temperatures (dynamic: > 64 KB for 8 waves).
     extern __shared__ double s_dyn[];
-    __shared__ double s_pal_static[(PAL && !FUSED) ? kLanes * kPal : 2];
     __shared__ double s_pos_static[FUSED ? 2 : kLanes];
-    double *const s_pal = FUSED ? s_dyn : s_pal_static;
+    double *const s_pal = s_dyn;  // (dynamic: kLanes * na.pal_stride doubles)
     // FUSED, after the palettes: with 16 nodes per lane V = dt/C of every node, [M][kLanes] (read where it is used:
     // held in registers over the march it would push that variant out of the register file); (hs * area, face temperature)
     // per side [2][kLanes] double2; zone temperatures, a0, b0, volume [kFusedMaxZones] each; first slot of every
     // zone [kFusedMaxZones + 1]; the slot lists.
     constexpr bool kVinLds = FUSED && M == 16;
-    double *const s_V = s_dyn + kLanes * kPal;
+    double *const s_V = s_dyn + kLanes * na.pal_stride;
     FusedLds fl;
     fl.hT = reinterpret_cast<double2 *>(s_V + (kVinLds ? M : 0) * kLanes);
     fl.zT = reinterpret_cast<double *>(fl.hT) + 4 * kLanes;
@@ -1158,7 +1164,7 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
                   const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                   const double *__restrict__ zone_T, int *__restrict__ flags,
                   unsigned long long *__restrict__ nomass_iters) {
-    __shared__ double s_pal[4 * kWave * kPal];
+    extern __shared__ double s_pal[];  // 4 * kWave * na.pal_stride doubles
     __shared__ double s_pos[4 * kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x >> 6;
@@ -1702,6 +1708,8 @@ __global__ void k_set_step(int *step_ptr, int v, int last) {
 // ---------------------------------------------------------------------------
 // Launch wrappers (host).
 static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
+// dynamic LDS of the streamed palette kernels: the palettes of a 256-lane workgroup's tiles
+static inline size_t pal_lds_bytes(const NodeArrays &na) { return (size_t)4 * kWave * na.pal_stride * sizeof(double); }
 
 void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
                           const NodeArrays &na,
@@ -1727,7 +1735,7 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     const dim3 grid(persistent ? std::min(full_grid, n_cu * blocks_per_cu) : full_grid), block(256);
     const FusedArgs no_fa{};
 #define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                          \
-    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC, 0>), grid, block, 0, st, tiles, n_tiles, na, sa, weather, \
+    hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC, 0>), grid, block, PP ? pal_lds_bytes(na) : 0, st, tiles, n_tiles, na, sa, weather, \
                        step_ptr, step_fixed, zone_T, flags, nomass_iters, no_fa)
 #define HEAT_LAUNCH_M(MM)                                     \
     switch ((nm ? 3 : 0) + (cav ? 2 : (pal ? 1 : 0))) {       \
@@ -1756,14 +1764,14 @@ void launch_surfaces_stream(const FastTile *tiles, int n_tiles, const NodeArrays
     }();
     static const int per_cu = getenv("HEAT_AMD_STREAM_BLOCKS") ? atoi(getenv("HEAT_AMD_STREAM_BLOCKS")) : 2;
     const int grid = std::min(blocks_for_waves(n_tiles), n_cu * std::max(per_cu, 1));
-    hipLaunchKernelGGL(k_surfaces_stream, dim3(grid), dim3(256), 0, st, tiles, n_tiles, na, gen_base, sa, weather, step_ptr,
+    hipLaunchKernelGGL(k_surfaces_stream, dim3(grid), dim3(256), pal_lds_bytes(na), st, tiles, n_tiles, na, gen_base, sa, weather, step_ptr,
                        step_fixed, zone_T, flags, nomass_iters);
 }
 
 // Cluster-resident march of one class: one workgroup of `max_waves` (4 or 8) wavefronts per FusedBlock, fa.n_sub
 // sub-timesteps in one launch. Palette classes without cavities only.
-size_t fused_lds_bytes(int max_waves, int M) {
-    return (size_t)max_waves * kWave * ((kPal + (M == 16 ? M : 0)) * sizeof(double) + 2 * sizeof(double2)) +
+size_t fused_lds_bytes(int max_waves, int M, int pal_stride) {
+    return (size_t)max_waves * kWave * ((pal_stride + (M == 16 ? M : 0)) * sizeof(double) + 2 * sizeof(double2)) +
            4 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
 }
 
@@ -1771,15 +1779,15 @@ template <int MM, int NN, int CC, int FW, int SM>
 static hipError_t launch_fused_one(int grid_blocks, const FastTile *tiles, int n_tiles, const NodeArrays &na,
                                    const SideArrays &sa, const StepWeather *weather, int *flags,
                                    unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
-    const size_t lds = fused_lds_bytes(FW, MM);
-    static bool attr_set = false;  // (per instantiation) dynamic LDS above the 64 KB default needs the attribute
-    if (!attr_set) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, CC, FW, SM>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
+    const size_t lds = fused_lds_bytes(FW, MM, na.pal_stride);
+    // (per instantiation) dynamic LDS above the 64 KB default needs the attribute; it grows with the palette width
+    static std::atomic<size_t> attr_bytes{64 * 1024};
+    if (lds > 160 * 1024) return hipErrorInvalidValue;  // (the planner keeps wide-palette 16-node clusters to four waves)
+    if (lds > attr_bytes.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, CC, FW, SM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_bytes.store(lds, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW, SM>), dim3(grid_blocks), dim3(kWave * FW), lds, st, tiles,
                        n_tiles, na, sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
@@ -1790,10 +1798,10 @@ static hipError_t launch_fused_one(int grid_blocks, const FastTile *tiles, int n
 // (no-mass facings allowed, gas cavities allowed up to 8 nodes per lane).
 // How many workgroups of a fused variant one compute unit holds (two waves per SIMD by registers; three for the
 // plain 4-node variants), also bounded by LDS.
-int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves) {
+int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves, int pal_stride) {
     const int waves_per_simd = (M == 4 && !cav && !mixed) ? 3 : 2;
     const int by_regs = std::max(1, waves_per_simd * 4 / max_waves);
-    const int by_lds = std::max<int>(1, (int)(160 * 1024 / fused_lds_bytes(max_waves, M)));
+    const int by_lds = std::max<int>(1, (int)(160 * 1024 / fused_lds_bytes(max_waves, M, pal_stride)));
     return std::min(by_regs, by_lds);
 }
 

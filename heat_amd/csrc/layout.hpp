@@ -109,19 +109,31 @@ struct SideArrays {
 
 // Unified per-node buffers (all groups).
 // Palette form of the per-node constants (fast classes with PAL = 1): a wall has only a handful of
-// distinct V = dt/mass and U values (one pair per layer, plus joints and end nodes), so each node
-// stores a one-byte class  c = vclass | uclass << 3  and each surface a palette of
-// kPalV V-values followed by kPalU U-values (entry 0 of both is 0.0: padding, no-mass, Back).
-constexpr int kPalV = 8;
-constexpr int kPalU = 4;
-constexpr int kPal = kPalV + kPalU;  // doubles per surface
+// distinct V = dt/mass and U values (per layer one of each, plus a V per joint and end node), so each node
+// stores a one-byte class and each surface a palette of V-values followed by U-values (entry 0 of both is 0.0:
+// padding, no-mass, Back). The class byte:
+//   bits 0-3  index of V; 14 and 15 mark the first node of a no-mass chunk of one / of two nodes (V = 0)
+//   bits 4-6  index of U
+// The batch's palettes are stored in the width its walls need (NodeArrays::pal_stride, pal_ubase):
+//   narrow  8 V + 4 U = 12 doubles (96 bytes per surface): walls of up to three layers — the synthetic workloads
+//   wide   16 V + 8 U = 24 doubles (192 bytes per surface): up to 13 distinct V and 7 distinct U — walls of six
+//          different layers (render / brick / insulation / block / service gap / plaster) stay in palette form, and
+//          with it candidates for the cluster-resident march
+constexpr int kPalV = 16;            // wide (what index fields and limits are sized for)
+constexpr int kPalU = 8;
+constexpr int kPal = kPalV + kPalU;
+constexpr int kPalVNarrow = 8;
+constexpr int kPalUNarrow = 4;
+constexpr int kPalNarrow = kPalVNarrow + kPalUNarrow;
+constexpr int kPalVMark1 = 14;       // V index values that are chunk marks; V entries usable: 0 .. 13
+constexpr int kPalUShift = 4;
 
 struct NodeArrays {
     double *T;               // node temperatures (state)
     const double *V;         // dt / mass for massive nodes, 0 for no-mass and padding
     const double *U;         // Solid u, 0 for Back/padding (cavity segments: 0, see cav)
     const uint8_t *cls;      // PAL classes: class byte of node (lane l, j) at node_base + l * M + j
-    const double *pal;       // PAL classes: palette of device surface d at pal + d * kPal
+    const double *pal;       // PAL classes: palette of device surface d at pal + d * pal_stride
     const int32_t *cavref;   // CAV classes: per device surface {node, cavity, node, cavity}: up to two gas
                              // cavities between massive nodes (segment node -> node+1), -1 = none
     const struct CavityDev *cavs;
@@ -129,6 +141,8 @@ struct NodeArrays {
     const double *alpha_b;
     const int32_t *cav;      // general group only: cavity index or -1
     const double *mass;      // general group only: raw thermal mass
+    int32_t pal_stride;      // doubles per palette: kPalNarrow or kPal
+    int32_t pal_ubase;       // where its U entries start: kPalVNarrow or kPalV
 };
 
 struct CavityDev {

@@ -57,6 +57,7 @@ struct Category {
     int pal;   // fast: the per-node constants fit a palette
     int m_ok;  // fast: blocking factors whose lanes hold every chunk whole (bit 0: 4, bit 1: 8, bit 2: 16 nodes per lane)
     int chunky = 0;  // fast: has chunks other than one-node facings (inside the wall, or of two nodes)
+    int wide = 0;    // fast, palette form: needs the wide palette (more than 8 V or 4 U entries, with the 0.0 of entry 0)
 };
 inline int m_bit(int M) { return M == 4 ? 1 : (M == 8 ? 2 : 4); }
 
@@ -117,9 +118,9 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
     if (m_ok == 0) return r;
     // Palette form when the wall has few distinct constants (entry 0 of each palette is 0.0).
     int pal = opt.no_palette ? 0 : 1;
+    int nu = 1, nv = 1;
     if (pal) {
         double vv[kPalV], uu[kPalU];
-        int nv = 1, nu = 1;
         vv[0] = 0.0;
         uu[0] = 0.0;
         for (int i = 0; i < n && pal; i++) {
@@ -128,7 +129,7 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
             const double u = is_cav(i) ? 0.0 : d->uvalue[o + i];
             int f = -1;
             for (int q = 0; q < nv; q++) if (vv[q] == v) f = q;
-            if (f < 0) { if (nv == kPalV) pal = 0; else vv[nv++] = v; }
+            if (f < 0) { if (nv == kPalVMark1) pal = 0; else vv[nv++] = v; }  // (indices 14, 15 are chunk marks)
             f = -1;
             for (int q = 0; q < nu; q++) if (uu[q] == u) f = q;
             if (f < 0) { if (nu == kPalU) pal = 0; else uu[nu++] = u; }
@@ -142,6 +143,7 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
     r.pal = pal;
     r.m_ok = m_ok;
     r.chunky = (nm && !facings_only) ? 1 : 0;
+    r.wide = (pal && (nv > kPalVNarrow || nu > kPalUNarrow)) ? 1 : 0;
     return r;
 }
 
@@ -360,6 +362,10 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             return (double)((n + m - 1) / m);
         };
         const int ms_all[3] = {4, 8, 16};
+        // LDS: with wide palettes (layout.hpp) a workgroup of eight 16-node wavefronts would need 180 KB
+        bool wide_batch = false;
+        for (int64_t s = 0; s < S; s++) wide_batch = wide_batch || (cat[s].kind == 0 && cat[s].wide);
+        auto max_tiles = [&](int m) { return (m == 16 && wide_batch) ? 4 : kFusedMaxWaves; };
         for (int64_t r = 0; r < Z; r++) {
             if (find((int32_t)r) != r || !cok[r] || coff[r + 1] == coff[r]) continue;
             // one blocking factor for the cluster: the cheapest that keeps every surface at two lanes or more
@@ -391,7 +397,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                     }
                     if (!ok) continue;
                     const int nt_m = tiles_needed_packed(c_k) + small_tiles(n_small);
-                    if (nt_m > kFusedMaxWaves) continue;
+                    if (nt_m > max_tiles(m)) continue;
                     const double t = cluster_ns(m, nt_m);
                     if (M == 0 || t <= best_cost) { M = m; best_cost = t; }
                 }
@@ -409,7 +415,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 nm |= cat[csurf[q]].nm;
             }
             const int nz = (int)czones[r].size();
-            if (!fits || tiles_needed_packed(cnt) + small_tiles(n_small) > kFusedMaxWaves || nz > kFusedMaxZones ||
+            if (!fits || tiles_needed_packed(cnt) + small_tiles(n_small) > max_tiles(M) || nz > kFusedMaxZones ||
                 ne > kFusedMaxEntries)
                 continue;  // streamed
             if (!fuse_always) {
@@ -684,7 +690,13 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     // ---- per-node constants ----
     std::vector<double> hV(node_cursor, 0.0), hU(node_cursor, 0.0);
     std::vector<uint8_t> hCls(p.n_palette ? node_cursor : 0, 0);
-    std::vector<double> hPal(p.n_palette ? (size_t)S * kPal : 0, 0.0);
+    // the palette width of the batch (layout.hpp): narrow unless a palette-form wall needs more entries
+    p.pal_stride = kPalNarrow;
+    for (int64_t s = 0; s < S; s++)
+        if (placed[s].cls < kNumFast && kFastPAL[placed[s].cls] && cat[s].wide) p.pal_stride = kPal;
+    p.pal_ubase = (p.pal_stride == kPal) ? kPalV : kPalVNarrow;
+    const int pstride = p.pal_stride, ubase = p.pal_ubase;
+    std::vector<double> hPal(p.n_palette ? (size_t)S * pstride : 0, 0.0);
     const int64_t gen_slots = node_cursor - p.gen_base;
     std::vector<double> hAf(gen_slots, 0.0), hAb(gen_slots, 0.0), hMass(gen_slots, 0.0);
     std::vector<int32_t> hCav(gen_slots, -1);
@@ -695,7 +707,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         const bool gen = placed[s].cls >= kNumFast;
         const bool pal = !gen && kFastPAL[placed[s].cls];
         int nv = 1, nu = 1;
-        double *pp = pal ? &hPal[(size_t)dd * kPal] : nullptr;
+        double *pp = pal ? &hPal[(size_t)dd * pstride] : nullptr;
         for (int i = 0; i < n; i++) {
             const int64_t idx = node_index(dd, i);
             const double mass = d->mass[o + i];
@@ -706,11 +718,11 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 int vc = -1, uc = -1;
                 for (int q = 0; q < nv; q++) if (pp[q] == hV[idx]) vc = q;
                 if (vc < 0) { vc = nv; pp[nv++] = hV[idx]; }
-                for (int q = 0; q < nu; q++) if (pp[kPalV + q] == hU[idx]) uc = q;
-                if (uc < 0) { uc = nu; pp[kPalV + nu++] = hU[idx]; }
+                for (int q = 0; q < nu; q++) if (pp[ubase + q] == hU[idx]) uc = q;
+                if (uc < 0) { uc = nu; pp[ubase + nu++] = hU[idx]; }
                 const NodeMap &m = nmap[dd];
                 const int lane = m.lane0 + i / m.M, j = i % m.M;
-                hCls[m.base + (int64_t)lane * m.M + j] = (uint8_t)(vc | (uc << 3));
+                hCls[m.base + (int64_t)lane * m.M + j] = (uint8_t)(vc | (uc << kPalUShift));
             }
             if (gen) {
                 const int64_t gi = idx - p.gen_base;
@@ -724,7 +736,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         nodeN_index[s] = node_index(dd, n - 1);
     }
 
-    // ---- no-mass chunk marks: bits 5-6 of the class byte of a chunk's first node = its node count (kernels.hip) ----
+    // ---- no-mass chunk marks: V index 14 / 15 in the class byte of a chunk's first node = one / two nodes (kernels.hip) ----
     if (!hCls.empty())
         for (int64_t dd = 0; dd < S; dd++) {
             const int64_t s = orig_of[dd];
@@ -735,7 +747,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 if (d->mass[o + i] >= kMassThreshold) { i++; continue; }
                 int e = i;
                 while (e < placed[s].n && d->mass[o + e] < kMassThreshold) e++;
-                hCls[m.base + (int64_t)(m.lane0 + i / m.M) * m.M + i % m.M] |= (uint8_t)((e - i) << 5);
+                hCls[m.base + (int64_t)(m.lane0 + i / m.M) * m.M + i % m.M] |= (uint8_t)(kPalVMark1 - 1 + (e - i));  // (its V index is 0)
                 i = e;
             }
         }
@@ -1042,7 +1054,9 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
     PLAN_REQUIRE((int64_t)p.side.size() == 2 * S && (int64_t)p.meta.size() == S, "side / meta size");
     PLAN_REQUIRE((int64_t)p.V.size() == p.node_slots && (int64_t)p.U.size() == p.node_slots, "V / U size");
     PLAN_REQUIRE(p.cls.empty() || (int64_t)p.cls.size() == p.node_slots, "class bytes size");
-    PLAN_REQUIRE(p.pal.empty() || (int64_t)p.pal.size() == S * kPal, "palette size");
+    PLAN_REQUIRE((p.pal_stride == kPalNarrow && p.pal_ubase == kPalVNarrow) || (p.pal_stride == kPal && p.pal_ubase == kPalV),
+                 "palette stride %d, U entries from %d", p.pal_stride, p.pal_ubase);
+    PLAN_REQUIRE(p.pal.empty() || (int64_t)p.pal.size() == S * p.pal_stride, "palette size");
     // tiles: every device surface in exactly one tile; node ranges inside the buffers and disjoint
     std::vector<uint8_t> covered(S, 0);
     std::vector<std::pair<int64_t, int64_t>> ranges;
@@ -1085,8 +1099,9 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
                     for (int i = 0; i < n; i++) {
                         const int lane = lane0 + i / M, j = i % M;
                         const uint8_t cb = p.cls[ft.node_base + (int64_t)lane * M + j];
-                        PLAN_REQUIRE((cb & 7) < kPalV && ((cb >> 3) & 3) < kPalU && (cb >> 5) <= 2 &&
-                                     ((cb >> 5) != 2 || j + 1 < M), "class byte %d", (int)cb);
+                        const int vi = cb & (kPalV - 1), ui = (cb >> kPalUShift) & (kPalU - 1);
+                        PLAN_REQUIRE((vi < p.pal_ubase || vi >= kPalVMark1) && ui < p.pal_stride - p.pal_ubase && cb < 128 &&
+                                     (vi != kPalVMark1 + 1 || j + 1 < M), "class byte %d", (int)cb);
                     }
                 }
                 if (mixed) lane0 += ks;

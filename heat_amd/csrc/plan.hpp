@@ -56,6 +56,8 @@ struct Plan {
     // per-node constants (device layout)
     std::vector<double> V, U, alpha_f, alpha_b, mass, pal;
     std::vector<uint8_t> cls;
+    int pal_stride = kPalNarrow;  // doubles per palette, and where its U entries start (layout.hpp)
+    int pal_ubase = kPalVNarrow;
     std::vector<int32_t> cav_idx, cavref;
     std::vector<CavityDev> cavs;
 

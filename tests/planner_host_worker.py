@@ -37,6 +37,22 @@ def main(path):
         for opts in (dict(), dict(fuse_always=True), dict(no_fusion=True)):
             binding.plan_check(md, lib=L, **opts)
             n_plans += 1
+    # walls of many materials (wide palettes, layout.hpp; beyond them per-node constants), with and without facings
+    for seed, layers in ((3, 5), (4, 6), (5, 9)):
+        md, _ = random_zone_graph_model(seed)
+        rng = np.random.default_rng(seed)
+        off = md["node_offset"]
+        mass, u = md["mass"].copy(), md["uvalue"].copy()
+        for s_ in range(0, md["n_surfaces"], 2):
+            n = int(off[s_ + 1] - off[s_])
+            for layer in range(layers):
+                a, b_ = off[s_] + n * layer // layers, off[s_] + n * (layer + 1) // layers
+                mass[a:b_] *= rng.uniform(0.7, 1.3)
+                u[a:b_] *= rng.uniform(0.7, 1.3)
+        md["mass"], md["uvalue"] = mass, u
+        for opts in (dict(), dict(no_fusion=True), dict(fuse_always=True), dict(fuse_always=True, nodes_per_lane=16)):
+            binding.plan_check(md, lib=L, **opts)
+            n_plans += 1
     # degenerate descriptors
     md, _ = mdl.uniform_massive(0, 8, Z=0)
     binding.plan_check(md, lib=L)

@@ -157,7 +157,7 @@ def test_nomass_chunks_inside_the_wall_and_of_two_nodes_on_the_fast_path(oracle,
              "insulation and lining inside": [conc, wool, poly],
              "cavity wall": [brick, wool, poly, brick],
              "both": [poly, wool, conc, wool, poly],
-             "facing and cavity": [poly, brick, poly, poly, conc, poly]}   # (three conductances: the palette's limit)
+             "facing and cavity": [poly, brick, poly, wool, conc, poly]}   # (more than three conductances: the wide palette)
     mds, states = [], []
     for name, lay in walls.items():
         lay = [dict(L, front_thermal_abs=0.2, back_thermal_abs=0.2, front_solar_abs=0.6, back_solar_abs=0.6) for L in lay]
@@ -456,19 +456,19 @@ def test_no_mass_facings_on_the_fast_path(oracle, n, npl, which):
 
 @pytest.mark.parametrize("npl", [0, 4, 8])
 def test_many_layer_walls_fall_back_to_per_node_constants(oracle, npl):
-    """Walls with more distinct dt/mass or U values than the palette holds (8 / 4) keep per-node arrays;
-    walls within the limit use the palette; both in one batch, bitwise equal to the no-palette build."""
+    """Walls with more distinct dt/mass or U values than the wide palette holds (13 / 7, layout.hpp) keep per-node
+    arrays; walls within the limit use the palette; both in one batch, bitwise equal to the no-palette build."""
     md, st = mdl.uniform_massive(400, 24, Z=4, dt=45.0, seed=77)
     off = md["node_offset"]
     rng = np.random.default_rng(5)
     mass = md["mass"].copy()
     u = md["uvalue"].copy()
-    for s_ in range(0, 400, 2):  # every other wall: 6 layers of 4 nodes with their own material
+    for s_ in range(0, 400, 2):  # every other wall: 8 layers of 3 nodes with their own material
         o = off[s_]
-        for layer in range(6):
+        for layer in range(8):
             f = rng.uniform(0.7, 1.3)
-            mass[o + 4 * layer:o + 4 * layer + 4] *= f
-            u[o + 4 * layer:o + 4 * layer + 4] *= rng.uniform(0.7, 1.3)
+            mass[o + 3 * layer:o + 3 * layer + 3] *= f
+            u[o + 3 * layer:o + 3 * layer + 3] *= rng.uniform(0.7, 1.3)
         u[off[s_ + 1] - 1] = 0.0
     md["mass"], md["uvalue"] = mass, u
     w = mdl.weather_series(15, 45.0)
@@ -721,6 +721,39 @@ def test_cluster_resident_march_config2_and_lone_surfaces(oracle):
     assert_state_close(md, ref, got)
     with HeatBatch(md, fuse_always=True) as b:
         assert b.n_fused_surfaces == 300
+
+
+def test_walls_of_many_materials_keep_the_palette_and_the_resident_march(oracle):
+    """A wall of five or six materials (render / brick / insulation / block / plaster) has more distinct conductances
+    than the narrow palette holds; the batch then stores 16-double palettes (layout.hpp kPal) and the wall stays in
+    the register kernel and in the fused clusters. Narrow and wide batches give the same numbers for narrow walls."""
+    mats = [dict(thickness=0.02, k=0.9, rho=1800., cp=840.), dict(thickness=0.11, k=0.6, rho=1600., cp=840.),
+            dict(thickness=0.08, k=0.25, rho=600., cp=1000.), dict(thickness=0.14, k=0.51, rho=1400., cp=1000.),
+            dict(thickness=0.06, k=1.4, rho=2100., cp=880.), dict(thickness=0.015, k=0.4, rho=1000., cp=1000.)]
+    mats = [dict(L, front_thermal_abs=0.9, back_thermal_abs=0.9, front_solar_abs=0.6, back_solar_abs=0.6) for L in mats]
+    for nl, copies in ((5, 96), (6, 64)):
+        d = oracle.discretize(mats[:nl], 600., 0.03, 60., 1., math.pi / 2)
+        assert len(set(np.round(d["uvalue"], 12))) > 4, d["uvalue"]       # (entry 0 of the palette is 0.0)
+        assert not oracle.get_chunks(d["mass"])[1]                         # all massive
+        dt = 600. / d["tstep_subdivision"]
+        md, st = surfaces_model(d, dt, mdl.OUTDOOR, mdl.SPACE, n_zones=4, zone_volume=[60.] * 4, front_emis=0.9,
+                                back_emis=0.9, area=10., perimeter=13., cos_tilt=0.0, normal=(0., 1., 0.), copies=copies)
+        md["back_zone"] = (np.arange(copies) % 4).astype(np.int32)
+        rng = np.random.default_rng(nl)
+        mdl.perturb_initial_temperatures(md, st, rng)
+        st[md["solar_front_slot"]] = rng.uniform(0., 500., copies)
+        mdl.set_ir_from_air(md, st, 5.0)
+        w = mdl.weather_series(24, dt, wind_speed=3.0, wind_deg=200.0)
+        ref, got, _, _, counts = run_both(oracle, md, st, w, np.full(4, 30.), np.full(4, 1.0))
+        assert counts[3] == 0 and counts[4] == 0, counts                   # nothing in the one-lane kernels
+        assert_state_close(md, ref, got)
+        with HeatBatch(md) as b:
+            assert b.n_fused_surfaces == copies
+        streamed = st.copy()
+        with HeatBatch(md, no_fusion=True) as b:
+            b.upload_state(streamed)
+            b.march(streamed, w, np.full(4, 30.), np.full(4, 1.0))
+        assert np.allclose(got, streamed, rtol=1e-10, atol=1e-10)
 
 
 def test_cluster_resident_march_with_gas_cavities(oracle):
