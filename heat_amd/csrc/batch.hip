@@ -1101,22 +1101,17 @@ int heat_batch_set_weather(heat_batch *b, const heat_weather *weather, int32_t n
                                       std::sin(weather[i].wind_direction), std::cos(weather[i].wind_direction)};
     }
     b->n_weather = n_sub;
-    if (n_sub > 0)
-        HIP_TRY(hipMemcpyAsync(b->d_weather.p, b->h_weather, (size_t)n_sub * sizeof(StepWeather),
-                               hipMemcpyHostToDevice, b->stream));
     const int64_t Z = b->n_zones;
-    if (Z > 0) {
-        for (int64_t z = 0; z < Z; z++) {
-            b->h_zone_ab[z] = zone_a0 ? zone_a0[z] : 0.0;
-            b->h_zone_ab[Z + z] = zone_b0 ? zone_b0[z] : 0.0;
-        }
-        HIP_TRY(hipMemcpyAsync(b->d_zone_a0.p, b->h_zone_ab, Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->d_zone_b0.p, b->h_zone_ab + Z, Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    for (int64_t z = 0; z < Z; z++) {
+        b->h_zone_ab[z] = zone_a0 ? zone_a0[z] : 0.0;
+        b->h_zone_ab[Z + z] = zone_b0 ? zone_b0[z] : 0.0;
     }
+    // weather, a0, b0 and the sub-timestep counter in one launch that reads the pinned buffers itself
+    launch_begin_march(b->h_weather, b->d_weather.p, n_sub, b->h_zone_ab, b->d_zone_a0.p, b->d_zone_b0.p, (int)Z, b->d_step.p,
+                       b->stream);
     if (!b->ev_staged) HIP_TRY(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->ev_staged, b->stream));
     b->staged = true;
-    launch_set_step(b->d_step.p, 0, n_sub - 1, b->stream);
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
 }

@@ -1705,6 +1705,24 @@ __global__ void k_set_step(int *step_ptr, int v, int last) {
     step_ptr[1] = last;
 }
 
+// The head of a march call in one launch: the call's weather and the zones' a0 / b0 terms from the pinned host staging
+// buffers (read over PCIe by the kernel itself: three small copies on the stream cost 30-50 us of idle chip per call
+// between them and the first kernel), and the sub-timestep counter.
+__global__ void k_begin_march(const StepWeather *__restrict__ h_weather, StepWeather *__restrict__ weather, int n_sub,
+                              const double *__restrict__ h_zone_ab, double *__restrict__ a0, double *__restrict__ b0,
+                              int n_zones, int *step_ptr, int last) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sub) weather[i] = h_weather[i];
+    if (i < n_zones) {
+        a0[i] = h_zone_ab[i];
+        b0[i] = h_zone_ab[n_zones + i];
+    }
+    if (i == 0) {
+        step_ptr[0] = 0;
+        step_ptr[1] = last;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Launch wrappers (host).
 static inline int blocks_for_waves(int n_waves) { return (n_waves + 3) / 4; }
@@ -1923,6 +1941,13 @@ void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const i
     const int n = std::max(n_surf, n_zones);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_outputs_compact, dim3((n + 255) / 256), dim3(256), 0, st, n_surf, n_zones, out, orig_of, zone_T, dst);
+}
+
+void launch_begin_march(const StepWeather *h_weather, StepWeather *weather, int n_sub, const double *h_zone_ab, double *a0,
+                        double *b0, int n_zones, int *step_ptr, hipStream_t st) {
+    const int n = std::max(std::max(n_sub, n_zones), 1);
+    hipLaunchKernelGGL(k_begin_march, dim3((n + 255) / 256), dim3(256), 0, st, h_weather, weather, n_sub, h_zone_ab, a0, b0,
+                       n_zones, step_ptr, n_sub - 1);
 }
 
 void launch_set_step(int *step_ptr, int v, int last, hipStream_t st) {

@@ -55,6 +55,8 @@ void launch_inputs_compact(int n_surf, int n_zones, const double *in, const doub
                            const SlotArrays &sl, double *mirror, hipStream_t st);
 void launch_outputs_compact(int n_surf, int n_zones, const SideOut *out, const int32_t *orig_of, const double *zone_T,
                             double *dst, hipStream_t st);
+void launch_begin_march(const StepWeather *h_weather, StepWeather *weather, int n_sub, const double *h_zone_ab, double *a0,
+                        double *b0, int n_zones, int *step_ptr, hipStream_t st);
 void launch_set_step(int *step_ptr, int v, int last, hipStream_t st);
 
 }  // namespace heat
