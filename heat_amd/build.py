@@ -41,6 +41,21 @@ def build(force=False, verbose=False):
     return LIB
 
 
+STAMPS_LIB = os.path.join(LIB_DIR, "libheat_amd_stamps.so")
+
+
+def build_stamps(force=False):
+    """Diagnostic build (-DHEAT_STAMPS): the cluster-resident workgroups stamp their phases (kernels.hip, HEAT_STAMP).
+    Loaded through HEAT_AMD_LIB by tools/fused_phases.py only; not part of the product."""
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    if not force and os.path.exists(STAMPS_LIB) and os.path.getmtime(STAMPS_LIB) >= max(map(os.path.getmtime, deps)):
+        return STAMPS_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHEAT_STAMPS", "-o", STAMPS_LIB] +
+                          [os.path.join(CSRC, s) for s in SOURCES])
+    return STAMPS_LIB
+
+
 EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "march_walls.cpp")
 EXAMPLE_BIN = os.path.join(LIB_DIR, "march_walls")
 

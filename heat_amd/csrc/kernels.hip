@@ -107,6 +107,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Sums inside the rows of 16 lanes: lane 15 of every row holds its row's sum (the first four steps of wave_sum_f64).
+__device__ __forceinline__ double row_sum_f64(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);
+    v = dpp_add_f64<0x112, 0xf>(v);
+    v = dpp_add_f64<0x114, 0xf>(v);
+    v = dpp_add_f64<0x118, 0xf>(v);
+    return v;
+}
+
 __device__ __forceinline__ double from_prev_lane(double v) { return dpp_rotate_f64<0x13C>(v); }  // wave_ror:1
 __device__ __forceinline__ double from_next_lane(double v) { return dpp_rotate_f64<0x134>(v); }  // wave_rol:1
 
@@ -397,32 +406,60 @@ __device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const Fu
     __syncthreads();
 }
 
-// calculate_zones_abc + estimate_zones_future_temperatures for the block's zones, as k_zones does: the sides'
-// (hs A, T) pairs are in LDS; one wavefront per zone sums them in the reference's order (model.rs:562-585).
+// calculate_zones_abc + estimate_zones_future_temperatures for the block's zones (model.rs:489-597,650-674): the sides'
+// (hs A, T) pairs are in LDS. A workgroup with no more zones than wavefronts gives every zone a wavefront (k_zones'
+// summation tree). One with more zones (buildings: rooms joined by partitions, a dozen walls each) gives every zone
+// a ROW of 16 lanes — four zones per wavefront at a time, their sums, divisions and exponentials side by side in the
+// lanes instead of one zone after the other: the serial tail of the phase is what the other wavefronts wait for.
 __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int wib,
                                                  int n_waves, int lane, int &bad_all) {
     __syncthreads();
-#pragma clang loop unroll(disable)
-    for (int j = wib; j < blk.n_zones; j += n_waves) {
-        const int e0 = l.zoff[j], e1 = l.zoff[j + 1];
-        // (the capacitance does not wait for the sums: its division overlaps their LDS round trips)
-        const double tc = l.zT[j];
-        const double cz = zone_mcp(l.zvol[j], tc);  // model.rs:549-552
-        double a = 0.0, b = 0.0;
-        for (int e = e0 + lane; e < e1; e += kWave) {
-            const double2 ht = l.hT[l.slots[e]];
-            a += ht.x * ht.y;
-            b += ht.x;
+    auto finish = [&](int j, double a, double b, double tc, double cz) {
+        a += l.za0[j];
+        b += l.zb0[j];
+        double ft = tc;
+        if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * fa.dt / cz);  // model.rs:662-666
+        if (ft != ft) bad_all |= FLAG_NAN_ZONE;                                // model.rs:417-420
+        l.zT[j] = ft;
+    };
+    if (blk.n_zones <= n_waves) {
+        if (wib < blk.n_zones) {
+            const int j = wib;
+            const int e0 = l.zoff[j], e1 = l.zoff[j + 1];
+            // (the capacitance does not wait for the sums: its division overlaps their LDS round trips)
+            const double tc = l.zT[j];
+            const double cz = zone_mcp(l.zvol[j], tc);  // model.rs:549-552
+            double a = 0.0, b = 0.0;
+            for (int e = e0 + lane; e < e1; e += kWave) {
+                const double2 ht = l.hT[l.slots[e]];
+                a += ht.x * ht.y;
+                b += ht.x;
+            }
+            a = wave_sum_f64(a);
+            b = wave_sum_f64(b);
+            if (lane == 0) finish(j, a, b, tc, cz);
         }
-        a = wave_sum_f64(a);
-        b = wave_sum_f64(b);
-        if (lane == 0) {
-            a += l.za0[j];
-            b += l.zb0[j];
-            double ft = tc;
-            if (fabs(b) > 1e-9) ft = a / b + (tc - a / b) * exp(-b * fa.dt / cz);  // model.rs:662-666
-            if (ft != ft) bad_all |= FLAG_NAN_ZONE;                                // model.rs:417-420
-            l.zT[j] = ft;
+    } else {
+        const int row = lane >> 4, rl = lane & 15;
+#pragma clang loop unroll(disable)
+        for (int j0 = 0; j0 < blk.n_zones; j0 += 4 * n_waves) {  // (workgroup-uniform trip count)
+            const int j = j0 + 4 * wib + row;
+            const bool on = j < blk.n_zones;
+            const int jj = on ? j : 0;
+            const int e0 = l.zoff[jj], e1 = on ? l.zoff[jj + 1] : e0;
+            const double tc = l.zT[jj];
+            const double cz = zone_mcp(l.zvol[jj], tc);
+            double a = 0.0, b = 0.0;
+            for (int e = e0 + rl; __any(e < e1); e += 16) {  // (wave-uniform trip count: DPP below must not sit in divergent code)
+                if (e < e1) {
+                    const double2 ht = l.hT[l.slots[e]];
+                    a += ht.x * ht.y;
+                    b += ht.x;
+                }
+            }
+            a = row_sum_f64(a);
+            b = row_sum_f64(b);
+            if (on && rl == 15) finish(j, a, b, tc, cz);
         }
     }
     __syncthreads();
@@ -489,6 +526,24 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
 }
 #pragma clang fp contract(fast)
 
+// Diagnostic build only (heat_amd/build.py build_stamps, -DHEAT_STAMPS -> lib/libheat_amd_stamps.so; tools/fused_phases.py):
+// wavefront 0 of every cluster-resident workgroup stamps the shader clock at its phases and the 100 MHz real-time
+// clock at both ends into a buffer nothing else reads. In the product build no stamp exists.
+#ifdef HEAT_STAMPS
+constexpr int kStampsPerBlock = 8;
+__device__ unsigned long long g_stamps[65536 * kStampsPerBlock];
+#define HEAT_STAMP(k, real)                                                                                   \
+    do {                                                                                                      \
+        if constexpr (FUSED) {                                                                                \
+            if (threadIdx.x == 0 && (counter_index >> 2) < 65536)                                             \
+                g_stamps[(counter_index >> 2) * kStampsPerBlock + (k)] =                                      \
+                    (real) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                 \
+        }                                                                                                     \
+    } while (0)
+#else
+#define HEAT_STAMP(k, real) do { } while (0)
+#endif
+
 // One tile of a fast class: n_it sub-timesteps (one, unless FUSED) of its surfaces. The body of k_surfaces_fast and
 // of the fast-path cases of k_surfaces_stream.
 //   write_out      streamed: hs and the heat flows (model.rs:154-169) are observable after the LAST sub-timestep of a
@@ -506,6 +561,8 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                                                 bool write_out = true) {
     constexpr int kLanes = (FUSED ? FUSED : 4) * kWave;
     constexpr bool kVinLds = FUSED && M == 16;
+    HEAT_STAMP(4, true);
+    HEAT_STAMP(0, false);
     double2 *const s_hT = fl.hT;
     double *const s_zT = fl.zT;
     (void)s_hT; (void)s_zT; (void)s_V; (void)s_pos; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
@@ -674,6 +731,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     double aux[M];
     StepWeather w_next = weather[step0];
 
+    HEAT_STAMP(1, false);
 #pragma clang loop unroll(disable)
     for (int it = 0; it < n_it; it++) {  // sub-timesteps (one, unless FUSED)
     const StepWeather w = w_next;
@@ -1020,6 +1078,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
 
     if constexpr (FUSED) fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
     }  // sub-timesteps
+    HEAT_STAMP(2, false);
 
     if constexpr (FUSED) {
         if (active) {
@@ -1042,6 +1101,11 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         sd.out[S + d] = o;
     }
     if (active && bad_all) report_failure(flags, bad_all, (unsigned int)d);
+#ifdef HEAT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores acknowledged: what a retiring wavefront waits for)
+#endif
+    HEAT_STAMP(3, false);
+    HEAT_STAMP(5, true);
     if constexpr (NM) {
         // passes of the no-mass loop, summed per tile (one owner per slot: no atomics on a shared word)
         unsigned int tot = nm_passes;
@@ -1955,3 +2019,9 @@ void launch_set_step(int *step_ptr, int v, int last, hipStream_t st) {
 }
 
 }  // namespace heat
+
+#ifdef HEAT_STAMPS
+extern "C" int heat_debug_stamps(unsigned long long *dst, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(heat::g_stamps), (size_t)n_blocks * heat::kStampsPerBlock * sizeof(unsigned long long));
+}
+#endif
