@@ -732,16 +732,16 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     StepWeather w_next = weather[step0];
 
     HEAT_STAMP(1, false);
+    // The side record: FUSED fetches it again for every sub-timestep (an L1/L2 hit) instead of holding its 20 registers
+    // across the RK stages — at the END of the sub-timestep before, so that it travels while the zone balance is summed.
+    SideConst c_cur = c_load;
+    SideDyn dy_cur = dy_load;
 #pragma clang loop unroll(disable)
     for (int it = 0; it < n_it; it++) {  // sub-timesteps (one, unless FUSED)
     const StepWeather w = w_next;
     if constexpr (FUSED) w_next = weather[min(it + 1, n_it - 1)];  // fetched a whole sub-timestep ahead of its use
-    // The side record: FUSED fetches it again every sub-timestep (an L1/L2 hit) instead of holding its 20
-    // registers across the march.
-    int sidx_now = sidx;
-    if constexpr (FUSED) asm volatile("" : "+v"(sidx_now));
-    const SideConst c = FUSED ? sd.sc[sidx_now] : c_load;
-    const SideDyn dy = FUSED ? sd.dyn[sidx_now] : dy_load;
+    const SideConst c = c_cur;
+    const SideDyn dy = dy_cur;
     // get_boundary_temperature, model.rs:79-96 (FUSED: zone temperatures live in LDS)
     auto btemp = [&](const SideConst &cc, int lz) -> double {
         const int kind = cc.kind_n & 3;
@@ -1076,7 +1076,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     }
     bad_all |= bad;
 
-    if constexpr (FUSED) fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
+    if constexpr (FUSED) {
+        int sidx_next = sidx;
+        asm volatile("" : "+v"(sidx_next));  // (a fresh load, not the value of the pass before kept in registers)
+        c_cur = sd.sc[sidx_next];
+        dy_cur = sd.dyn[sidx_next];
+        fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
+    }
     }  // sub-timesteps
     HEAT_STAMP(2, false);
 
