@@ -378,10 +378,10 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
 // Cluster-resident march, pieces shared by the fast-path wavefronts and the small-surface wavefronts of a
 // workgroup (layout.hpp, FusedBlock). LDS after the palettes (and V): see k_surfaces_fast.
 struct FusedLds {
-    double2 *hT;            // (hs * area, face temperature) per side: [2][lanes]
+    double2 *hT;            // (hs * area, face temperature) of the zone-facing sides, in the order of the zones' lists
     double *zT, *za0, *zb0, *zvol;
     int *zoff;
-    unsigned short *slots;
+    unsigned short *slots;  // place in hT of side [2][lanes] (front sides, then back sides, by lane of the workgroup)
 };
 
 // Barriers a wavefront of a fused workgroup passes: one at the end of fused_block_init, two per sub-timestep in
@@ -402,7 +402,9 @@ __device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const Fu
         l.zvol[threadIdx.x] = fa.vol[z];
     }
     const int n_e = fa.zone_eoff[blk.first_zone + blk.n_zones] - e_first;
-    for (int e = threadIdx.x; e < n_e; e += n_threads) l.slots[e] = fa.slots[e_first + e];
+    // where every zone-facing side puts its (hs A, T) pair: at its entry's place in its zone's list, so that the sums
+    // below read the pairs in a row (the look-up is the writers' — all wavefronts, side by side — not the summing one's)
+    for (int e = threadIdx.x; e < n_e; e += n_threads) l.slots[fa.slots[e_first + e]] = (unsigned short)e;
     __syncthreads();
 }
 
@@ -431,7 +433,7 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
             const double cz = zone_mcp(l.zvol[j], tc);  // model.rs:549-552
             double a = 0.0, b = 0.0;
             for (int e = e0 + lane; e < e1; e += kWave) {
-                const double2 ht = l.hT[l.slots[e]];
+                const double2 ht = l.hT[e];
                 a += ht.x * ht.y;
                 b += ht.x;
             }
@@ -452,7 +454,7 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
             double a = 0.0, b = 0.0;
             for (int e = e0 + rl; __any(e < e1); e += 16) {  // (wave-uniform trip count: DPP below must not sit in divergent code)
                 if (e < e1) {
-                    const double2 ht = l.hT[l.slots[e]];
+                    const double2 ht = l.hT[e];
                     a += ht.x * ht.y;
                     b += ht.x;
                 }
@@ -508,8 +510,8 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
             double Tl = T[0];
 #pragma unroll
             for (int j = 1; j < kSmallNodes; j++) Tl = (j == nn - 1) ? T[j] : Tl;
-            if ((cf.kind_n & 3) == KIND_SPACE) l.hT[wib * kWave + lane] = make_double2(of.hs * area, T[0]);
-            if ((cb.kind_n & 3) == KIND_SPACE) l.hT[lanes_per_side + wib * kWave + lane] = make_double2(ob.hs * area, Tl);
+            if ((cf.kind_n & 3) == KIND_SPACE) l.hT[l.slots[wib * kWave + lane]] = make_double2(of.hs * area, T[0]);
+            if ((cb.kind_n & 3) == KIND_SPACE) l.hT[l.slots[lanes_per_side + wib * kWave + lane]] = make_double2(ob.hs * area, Tl);
         }
         fused_zone_phase(blk, fa, l, wib, n_waves, lane, bad_all);
     }
@@ -1058,7 +1060,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         }
         if constexpr (FUSED) {
             if (active && (is_first || is_last) && (c.kind_n & 3) == KIND_SPACE)
-                s_hT[(my_back ? kLanes : 0) + wib * kWave + lane] = make_double2(hs * my_area, face_t);
+                s_hT[fl.slots[(my_back ? kLanes : 0) + wib * kWave + lane]] = make_double2(hs * my_area, face_t);
         }
     }
     if (single) {
@@ -1069,7 +1071,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             if (active) put_zone_contrib(sd, cb2, hs, Tln);
         } else {
             if (active && (cb2.kind_n & 3) == KIND_SPACE)
-                s_hT[kLanes + wib * kWave + lane] = make_double2(hs * my_area, Tln);
+                s_hT[fl.slots[kLanes + wib * kWave + lane]] = make_double2(hs * my_area, Tln);
         }
     } else if (!(is_first || is_last)) {
         bad = 0;
