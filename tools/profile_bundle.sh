@@ -5,6 +5,7 @@
 # Writes under gpurun_out/<tag>_bundle/ and copies the summaries into profiles/ (to be committed).
 set -e
 tag=$1
+part=${2:-all}   # stats | counters | all (two gpurun calls when one is too long)
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 out=$R/gpurun_out/${tag}_bundle
@@ -17,11 +18,14 @@ stats() {  # name, bench args...
     cp $out/${name}_under_rocprof.json $R/profiles/${tag}_${name}_under_rocprof.json
     echo "stats $name done"
 }
+if [ "$part" != counters ]; then
 stats headline --steps 200 --warmup 20
 stats cfg3 --config 3 --steps 100 --warmup 20
 stats cfg5 --config 5 --steps 100 --warmup 20
 stats cfg2 --config 2 --steps 200 --warmup 20
 stats partitions --config partitions --steps 100 --warmup 20
+fi
+[ "$part" = stats ] && { echo "bundle $tag stats done"; exit 0; }
 # counters: tools/run_config.py CONFIG P REPS MODE
 $R/tools/pmc_passes.sh $out/pmc_headline_fused -- python3 $R/tools/run_config.py headline 20 2 plan
 python3 $R/tools/make_counters.py ${tag}_headline_fused $out/pmc_headline_fused "k_surfaces_fast<16, 0, 1, 0, 4" headline 1000000 32000000 fused 20
@@ -29,4 +33,10 @@ $R/tools/pmc_passes.sh $out/pmc_headline_streamed -- python3 $R/tools/run_config
 python3 $R/tools/make_counters.py ${tag}_headline_streamed $out/pmc_headline_streamed "k_surfaces_fast<16, 0, 1, 0, 0" headline 1000000 32000000 streamed 1
 $R/tools/pmc_passes.sh $out/pmc_cfg3 -- python3 $R/tools/run_config.py 3 10 1 stream
 python3 $R/tools/make_counters.py ${tag}_cfg3_streamed $out/pmc_cfg3 "k_surfaces_stream" 3 1000000 32609258 streamed 1
+$R/tools/pmc_passes.sh $out/pmc_partitions -- python3 $R/tools/run_config.py partitions 20 2 plan
+python3 $R/tools/make_counters.py ${tag}_partitions_fused $out/pmc_partitions "k_surfaces_fast<16, 0, 1, 0, 4" partitions 999936 31997952 fused 20
+# where a cluster-resident workgroup's time goes (diagnostic build with in-kernel stamps)
+python3 $R/tools/fused_phases.py headline 20 > $R/profiles/${tag}_fused_phases.txt
+python3 $R/tools/fused_phases.py headline 5 >> $R/profiles/${tag}_fused_phases.txt
+python3 $R/tools/fused_phases.py partitions 20 >> $R/profiles/${tag}_fused_phases.txt
 echo "bundle $tag done"
