@@ -225,6 +225,7 @@ struct heat_batch {
     DevBuf<int64_t> d_first_slot, d_slots;  // d_slots: 8 arrays of n_surf
     DevBuf<int64_t> d_zone_slot, d_zone_off;
     DevBuf<ZoneEntry> d_zone_entries;
+    int zone_rows = 0;  // k_zones gives a zone a row of 16 lanes (few walls per zone) instead of a wavefront
     DevBuf<ZoneContrib> d_zone_contrib;  // [zone entries], written by the surface kernels
     DevBuf<double> d_zone_vol, d_zone_T, d_zone_a0, d_zone_b0, d_partial;
     double *partial_ptr = nullptr;  // where step_surfaces writes (a, b): d_partial or caller memory
@@ -422,6 +423,10 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_zone_vol.upload(p.zone_vol));
     HIP_TRY(b->d_zone_off.upload(p.zone_off));
     HIP_TRY(b->d_zone_entries.upload(p.zone_entries));
+    {
+        static const char *rows_env = getenv("HEAT_AMD_ZONE_ROWS");  // measurement: 0 / 1 overrides the rule
+        b->zone_rows = rows_env ? atoi(rows_env) : ((int64_t)p.zone_entries.size() <= 24 * (int64_t)b->n_zones);
+    }
     HIP_TRY(b->d_zone_contrib.zeros(p.zone_entries.size()));
     HIP_TRY(b->d_zone_T.zeros(Z));
     HIP_TRY(b->d_zone_a0.zeros(Z));
@@ -680,7 +685,7 @@ void enqueue_zones(heat_batch *b, int mode) {
     if (mode == 4) { zl = b->d_zlist_stream.p; nl = b->n_touched_stream; mode = 2; }  // sharded, beside a fused march
     launch_zones(b->d_zone_off.p, b->d_zone_entries.p, b->d_zone_contrib.p, b->d_zone_a0.p, b->d_zone_b0.p,
                  b->d_zone_vol.p, b->d_zone_T.p, b->partial_ptr, (int)b->n_zones, b->dt, b->d_step.p,
-                 b->d_flags.p, mode, zl, nl, b->d_slot_of.p, b->n_shared, b->stream);
+                 b->d_flags.p, mode, zl, nl, b->d_slot_of.p, b->n_shared, b->zone_rows, b->stream);
 }
 
 // The cluster-resident march: every fused workgroup marches n_sub sub-timesteps in one launch per class.

@@ -1501,13 +1501,15 @@ k_surfaces_general(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArray
 
 
 // ---------------------------------------------------------------------------
-// Zones: one wavefront per zone.
+// Zones: one wavefront per zone (ROWS = 0), or — zones of a few walls each, buildings of small rooms — one ROW of 16
+// lanes per zone, four zones per wavefront (ROWS = 1: the sums, divisions and exponentials of four zones side by side).
 //   mode 0: every zone, full update (single GPU).
 //   mode 1: every zone, write the partial (a, b) into partial[2][n_zones] only.
 //   mode 3: as mode 0, but only the zones in zlist[n_list] (the others are owned by fused workgroups).
 //   mode 2: sharded: only the zones in zlist[n_list] (those this rank's surfaces touch); a zone no other rank
 //           touches (slot_of[z] < 0) is updated here and now, a shared one writes its partial (a, b) into the
 //           compact partial[2][n_shared] at its slot for the exchange.
+template <int ROWS>
 __global__ void __launch_bounds__(256)
 k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entries,
         const ZoneContrib *__restrict__ zc,
@@ -1515,12 +1517,13 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
         double *__restrict__ zone_T, double *__restrict__ partial, int n_zones, double dt,
         int *__restrict__ step_ptr, int *__restrict__ flags, int mode, const int32_t *__restrict__ zlist,
         int n_list, const int32_t *__restrict__ slot_of, int n_shared) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    constexpr int kW = ROWS ? 16 : kWave;  // lanes per zone
+    const int lane = threadIdx.x & (kW - 1);
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) / kW;
     if (blockIdx.x == 0 && threadIdx.x == 0 && (mode == 0 || mode == 3)) *step_ptr += 1;
     int z = wv;
     if (mode == 2 || mode == 3) {
-        if (wv >= n_list) return;
+        if (wv >= n_list) return;  // (whole rows leave: the row sums below stay inside a row)
         z = zlist[wv];
     }
     if (z >= n_zones) return;
@@ -1530,9 +1533,9 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
     const double za0 = a0[z], zb0 = b0[z], tc = zone_T[z], zv = zone_vol[z];
     // the surface kernels have left every side's (hs, face temperature) at its place in the zone's list: two
     // contiguous streams, two entries per lane and pass
-    for (int64_t e = e0 + lane; e < e1; e += 2 * kWave) {  // model.rs:562-585
-        const bool two = e + kWave < e1;
-        const int64_t e2 = two ? e + kWave : e;
+    for (int64_t e = e0 + lane; e < e1; e += 2 * kW) {  // model.rs:562-585
+        const bool two = e + kW < e1;
+        const int64_t e2 = two ? e + kW : e;
         const ZoneContrib c0 = zc[e], c1 = zc[e2];
         const double ha0 = c0.hs * entries[e].area;
         a += ha0 * c0.t_face;
@@ -1543,9 +1546,16 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
             b += ha1;
         }
     }
-    a = wave_sum_f64(a);  // fixed tree: run-to-run deterministic
-    b = wave_sum_f64(b);
-    if (lane != 0) return;
+    if constexpr (ROWS) {
+        // (the rows' loops above may differ in length: exec is whole again here, rows that left stay masked)
+        a = row_sum_f64(a);  // fixed tree: run-to-run deterministic; the row's sum in its lane 15
+        b = row_sum_f64(b);
+        if (lane != 15) return;
+    } else {
+        a = wave_sum_f64(a);
+        b = wave_sum_f64(b);
+        if (lane != 0) return;
+    }
     if (mode == 1) {
         partial[z] = a;
         partial[n_zones + z] = b;
@@ -1944,12 +1954,19 @@ void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_ti
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const ZoneContrib *zc,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
-                  const int32_t *slot_of, int n_shared, hipStream_t st) {
-    const int n_waves = (mode == 2 || mode == 3) ? n_list : n_zones;
-    if (mode == 2 && n_waves <= 0) return;
-    const int nb = n_waves > 0 ? blocks_for_waves(n_waves) : 1;
-    hipLaunchKernelGGL(k_zones, dim3(nb), dim3(256), 0, st, zone_off, entries, zc, a0, b0, zone_vol, zone_T,
-                       partial, n_zones, dt, step_ptr, flags, mode, zlist, n_list, slot_of, n_shared);
+                  const int32_t *slot_of, int n_shared, int rows, hipStream_t st) {
+    const int n_z = (mode == 2 || mode == 3) ? n_list : n_zones;
+    if (mode == 2 && n_z <= 0) return;
+    // rows: a zone per row of 16 lanes (the batch's zones have few walls each), else a zone per wavefront
+    if (rows) {
+        const int nb = n_z > 0 ? (n_z + 15) / 16 : 1;
+        hipLaunchKernelGGL(k_zones<1>, dim3(nb), dim3(256), 0, st, zone_off, entries, zc, a0, b0, zone_vol, zone_T,
+                           partial, n_zones, dt, step_ptr, flags, mode, zlist, n_list, slot_of, n_shared);
+    } else {
+        const int nb = n_z > 0 ? blocks_for_waves(n_z) : 1;
+        hipLaunchKernelGGL(k_zones<0>, dim3(nb), dim3(256), 0, st, zone_off, entries, zc, a0, b0, zone_vol, zone_T,
+                           partial, n_zones, dt, step_ptr, flags, mode, zlist, n_list, slot_of, n_shared);
+    }
 }
 
 void launch_zone_update_shared(const double *gathered, int n_blocks, const int32_t *shared_zone, int n_shared,

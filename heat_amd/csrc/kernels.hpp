@@ -36,7 +36,7 @@ void launch_surfaces_small(int with_cavities, const GeneralTile *tiles, int n_ti
 void launch_zones(const int64_t *zone_off, const ZoneEntry *entries, const ZoneContrib *zc,
                   const double *a0, const double *b0, const double *zone_vol, double *zone_T, double *partial,
                   int n_zones, double dt, int *step_ptr, int *flags, int mode, const int32_t *zlist, int n_list,
-                  const int32_t *slot_of, int n_shared, hipStream_t st);
+                  const int32_t *slot_of, int n_shared, int rows, hipStream_t st);
 void launch_zone_update_shared(const double *gathered, int n_blocks, const int32_t *shared_zone, int n_shared,
                                const double *a0, const double *b0, const double *zone_vol, double *zone_T,
                                double dt, int *flags, hipStream_t st);
