@@ -35,6 +35,8 @@ $R/tools/pmc_passes.sh $out/pmc_cfg3 -- python3 $R/tools/run_config.py 3 10 1 st
 python3 $R/tools/make_counters.py ${tag}_cfg3_streamed $out/pmc_cfg3 "k_surfaces_stream" 3 1000000 32609258 streamed 1
 $R/tools/pmc_passes.sh $out/pmc_partitions -- python3 $R/tools/run_config.py partitions 20 2 plan
 python3 $R/tools/make_counters.py ${tag}_partitions_fused $out/pmc_partitions "k_surfaces_fast<16, 0, 1, 0, 4" partitions 999936 31997952 fused 20
+$R/tools/pmc_passes.sh $out/pmc_cfg2 -- python3 $R/tools/run_config.py 2 20 5 plan
+python3 $R/tools/make_counters.py ${tag}_cfg2_fused $out/pmc_cfg2 "k_surfaces_fast<16, 0, 1, 0, 4" 2 10000 200000 fused 20
 # where a cluster-resident workgroup's time goes (diagnostic build with in-kernel stamps)
 python3 $R/tools/fused_phases.py headline 20 > $R/profiles/${tag}_fused_phases.txt
 python3 $R/tools/fused_phases.py headline 5 >> $R/profiles/${tag}_fused_phases.txt
