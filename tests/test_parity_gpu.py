@@ -341,6 +341,29 @@ def test_shards_of_the_cluster_partition_march_without_any_exchange(oracle, n_ra
     assert_state_close(md, ref, got)
 
 
+@pytest.mark.parametrize("rooms,n,kw", [(8, 20, {}), (8, 20, dict(no_fusion=True)), (8, 32, {}), (6, 9, {}),
+                                        (40, 20, {}), (16, 12, dict(fuse_always=True))])
+def test_buildings_of_small_rooms_joined_by_partitions(oracle, rooms, n, kw):
+    """Buildings as models have them (src/model.rs:556-590: a partition is in the balance of both rooms it separates):
+    rooms of a dozen walls, two of them interior partitions to the next room. A building is one cluster of `rooms`
+    zones: cluster-resident, its workgroup balances the zones side by side in rows of 16 lanes (more zones than
+    wavefronts); streamed — by choice, or because 40 rooms do not fit a workgroup — k_zones gives every zone a row of
+    16 lanes instead of a wavefront (few walls per zone)."""
+    per = rooms * 12
+    md, st = mdl.partitioned_buildings(5 * per, n, rooms=rooms, dt=45.0, seed=rooms + n)
+    Z = md["n_zones"]
+    rng = np.random.default_rng(rooms)
+    w = mdl.weather_series(13, 45.0, wind_speed=3.5, wind_deg=120.0)
+    a0 = rng.uniform(0., 60., Z)
+    b0 = rng.uniform(0.1, 2., Z)
+    ref, got, iters, gpu_iters, counts = run_both(oracle, md, st, w, a0, b0, **kw)
+    assert iters == gpu_iters
+    assert_state_close(md, ref, got)
+    with HeatBatch(md, **kw) as b:
+        fits = rooms <= 16 and "no_fusion" not in kw
+        assert (b.n_fused_surfaces == md["n_surfaces"]) == fits, (b.n_fused_surfaces, b.class_counts())
+
+
 @pytest.mark.parametrize("mode", ["planned", "streamed", "general"])
 def test_numerical_failure_names_the_surface(mode):
     """The reference's panic on a NaN convection coefficient names the values (surface.rs:704-707); the library
