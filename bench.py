@@ -393,6 +393,8 @@ def main():
             rl["frac"] = rl["achieved"] / VALU_PEAK_GINST
             rl["valu_insts_per_sub_timestep"] = valu
             rl["traffic"] = counters.get("hbm_traffic_bytes_per_launch")
+            if rl["traffic"]:  # (a rank of a sharded run launches its share of the counted workload)
+                rl["traffic"] *= nodes_local / counters["workload"]["nodes_total"]
             if rl["traffic"]:
                 rl["hbm_gbs_measured_traffic"] = rl["traffic"] / (surf_us * P * 1e-6) / 1e9
                 rl["hbm_frac_measured_traffic"] = rl["hbm_gbs_measured_traffic"] / HBM_PEAK_GBS
