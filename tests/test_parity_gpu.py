@@ -890,13 +890,17 @@ def test_config3_at_full_size_fast_kernels_equal_the_catch_all_kernel():
     assert np.allclose(res[0][0], res[1][0], rtol=1e-10, atol=1e-10)
 
 
-@pytest.mark.parametrize("config", ["headline", "3"])
+@pytest.mark.parametrize("config", ["headline", "3", "partitions"])
 def test_full_size_against_the_whole_oracle(oracle, config):
     """The oracle, threaded over the surfaces on the box's host cores (the reference's disabled rayon path,
-    model.rs:113-116), marches the FULL BASELINE sizes in seconds: 1 000 000 x 32 (cluster-resident march) and the
-    1 000 000 ragged mixed surfaces of config 3 (one streamed launch per sub-timestep) are compared slot by slot."""
+    model.rs:113-116), marches the FULL BASELINE sizes in seconds: 1 000 000 x 32 (cluster-resident march), the
+    1 000 000 ragged mixed surfaces of config 3 (one streamed launch per sub-timestep) and a million walls in buildings
+    of 8 rooms joined by partitions (cluster-resident, zones balanced in rows of 16 lanes) are compared slot by slot."""
     if config == "headline":
         md, st = mdl.uniform_massive(1_000_000, 32, Z=10_000, dt=45.0)
+        n_sub = 10
+    elif config == "partitions":
+        md, st = mdl.partitioned_buildings(1_000_000, 32, dt=45.0)
         n_sub = 10
     else:
         md, st = mdl.ragged_mixed(1_000_000, dt=45.0)
@@ -910,7 +914,7 @@ def test_full_size_against_the_whole_oracle(oracle, config):
     assert rc == 0
     got = st.copy()
     with HeatBatch(md, use_graph=True) as b:
-        assert (b.n_fused_surfaces > 0) == (config == "headline")
+        assert (b.n_fused_surfaces > 0) == (config != "3")
         b.upload_state(got)
         b.march(got, w, a0, b0)
     assert_state_close(md, ref, got)
