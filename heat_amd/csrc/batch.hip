@@ -295,6 +295,8 @@ struct heat_batch {
     bool fusion_on = true;     // heat_batch_options::no_fusion / heat_batch_set_fusion
     int64_t n_fused_launches = 0;  // cluster-resident launches issued since creation (introspection)
     bool graph_fused = false;  // what the captured sub-timestep graph leaves out
+    int graph_subs = 0;        // sub-timesteps one replay of the captured graph runs
+    int graph_recaptures = 0;  // captures forced by a change of the calls' length
 
     ~heat_batch() {
         if (comm) {
@@ -1485,17 +1487,32 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
             b->ev_triples.push_back({e0, e1, e2});
         }
     } else if (b->use_graph) {
-        if (!b->graph_exec || b->graph_fused != fused) {
+        // One graph holds a whole march call's sub-timesteps (up to 32; the usual call — ThermalModel::march runs a fixed
+        // dt_subdivisions of them — replays it once): inside a graph consecutive kernels follow each other closer than
+        // consecutive graph launches do. A call of another length re-captures; longer ones replay blocks.
+        static const int per_graph_env = getenv("HEAT_AMD_GRAPH_SUBSTEPS") ? atoi(getenv("HEAT_AMD_GRAPH_SUBSTEPS")) : 0;
+        // (a caller whose calls keep changing length gets the one-sub-timestep graph, which fits every length)
+        const int want = b->graph_recaptures > 8 ? 1 : (per_graph_env > 0 ? std::min(per_graph_env, n_sub) : std::min(n_sub, 32));
+        if (!b->graph_exec || b->graph_fused != fused || (b->graph_subs != want && n_sub % b->graph_subs != 0)) {
+            if (b->graph_exec && b->graph_fused == fused) b->graph_recaptures++;
             if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
             if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
             HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_surfaces(b, -1, fused);
-            enqueue_zones(b, zmode);
+            for (int i = 0; i < want; i++) {
+                enqueue_surfaces(b, -1, fused);
+                enqueue_zones(b, zmode);
+            }
             HIP_TRY(hipStreamEndCapture(b->stream, &b->graph));
             HIP_TRY(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
             b->graph_fused = fused;
+            b->graph_subs = want;
         }
-        for (int i = 0; i < n_sub; i++) HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+        int done = 0;
+        for (; done + b->graph_subs <= n_sub; done += b->graph_subs) HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+        for (; done < n_sub; done++) {  // (a remainder shorter than the graph: plain launches)
+            enqueue_surfaces(b, -1, fused);
+            enqueue_zones(b, zmode);
+        }
     } else {
         for (int i = 0; i < n_sub; i++) {
             enqueue_surfaces(b, -1, fused);
