@@ -452,7 +452,7 @@ class HeatBatch:
         return int(self._L.heat_batch_n_fused_launches(self._h))
 
     def set_timing(self, enabled):
-        _check(self._L.heat_batch_set_timing(self._h, 1 if enabled else 0))
+        _check(self._L.heat_batch_set_timing(self._h, int(enabled)))  # (k > 1: every k-th streamed march call)
 
     def get_timing(self):
         a, b, n = _d(0), _d(0), C.c_int64(0)

@@ -286,6 +286,8 @@ struct heat_batch {
 
     // timing
     bool timing = false;
+    int timing_every = 1;      // heat_batch_set_timing(k > 1): only every k-th streamed march call records events
+    int64_t timing_calls = 0;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct EvTriple { hipEvent_t e0, e1, e2; };            // one streamed sub-timestep: start, surfaces done, zones done
@@ -1475,7 +1477,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     const int zmode = fused ? 3 : (b->n_ranks > 1 ? 5 : 0);
     if (!streamed) {
         // nothing to stream
-    } else if (b->timing) {
+    } else if (b->timing && (b->timing_calls++ % b->timing_every) == 0) {
         for (int i = 0; i < n_sub; i++) {
             hipEvent_t e0 = next_event(b), e1 = next_event(b), e2 = next_event(b);
             if (!e0 || !e1 || !e2) return fail(HEAT_E_DEVICE, "hipEventCreate failed");
@@ -1598,6 +1600,8 @@ int64_t heat_batch_nomass_iterations(heat_batch *b) {
 int heat_batch_set_timing(heat_batch *b, int32_t enabled) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
     b->timing = enabled != 0;
+    b->timing_every = enabled > 1 ? enabled : 1;
+    b->timing_calls = 0;
     b->ev_used = 0;
     b->ev_triples.clear();
     b->ev_fused_pairs.clear();

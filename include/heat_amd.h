@@ -283,7 +283,9 @@ int heat_batch_class_counts(const heat_batch *b, int64_t counts[5]);
  * every sub-timestep executed while enabled (the march then runs eagerly, not as a graph).
  * heat_batch_get_timing synchronises and returns the mean duration in microseconds of the
  * surface kernels of one sub-timestep (*surf_us), of one whole sub-timestep (*substep_us) and
- * the number of sub-timesteps sampled; it then clears the samples. */
+ * the number of sub-timesteps sampled; it then clears the samples.
+ * enabled = k > 1: of the streamed march calls only every k-th one records events (and runs eagerly); the others
+ * replay the graph as they do untimed — the rate of a timed region then stays close to the untimed one. */
 int heat_batch_set_timing(heat_batch *b, int32_t enabled);
 int heat_batch_get_timing(heat_batch *b, double *surf_us, double *substep_us, int64_t *n_samples);
 
