@@ -413,6 +413,8 @@ def main():
         result["roofline"] = hbm_roofline(algorithmic_bytes, surf_us, substep_us, n_samples, counters, src,
                                           "streamed march: k_surfaces_stream / k_surfaces_fast (iterate_surfaces: RK4 stencil "
                                           "+ boundary updates, one sub-timestep per launch)")
+        # the same bytes over the wall-clock time of a step of the timed region (graph replay, launches and all)
+        result["roofline"]["frac_wall_clock_step"] = algorithmic_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS
     extras = rank == 0 and world == 1 and not sharded and not args.no_extras
     if extras:
         # the drop-in call on a caller-owned host state (PCIe-inclusive; never `value`)
