@@ -319,10 +319,10 @@ def main():
         march_in_calls(run, weather_w[:W], P)
     barrier()
     # HIP events around the kernels inside the timed region: every call of a cluster-resident march (two events per
-    # launch); of a streamed march every third call (three events per sub-timestep, issued eagerly — the other calls
-    # replay the hipGraph as an untimed march does)
+    # launch); of a streamed march ONE call in three, or the first call only when the region has fewer (three events per
+    # sub-timestep, issued eagerly — the other calls replay the hipGraph as an untimed march does)
     will_fuse = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if batch.n_surfaces_in_batch <= 8192 else 3)
-    batch.set_timing(0 if args.no_timing else (1 if will_fuse else 3))
+    batch.set_timing(0 if args.no_timing else (1 if will_fuse else max(3, -(-K // P))))
     t0 = time.perf_counter()
     march_in_calls(run, weather_k, P)
     barrier()
