@@ -1880,14 +1880,17 @@ static hipError_t launch_fused_one(int grid_blocks, const FastTile *tiles, int n
                                    const SideArrays &sa, const StepWeather *weather, int *flags,
                                    unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st) {
     const size_t lds = fused_lds_bytes(FW, MM, na.pal_stride);
-    // (per instantiation) dynamic LDS above the 64 KB default needs the attribute; it grows with the palette width
-    static std::atomic<size_t> attr_bytes{64 * 1024};
+    // (per instantiation and device) dynamic LDS above the 64 KB default needs the attribute; it grows with the palette width
+    constexpr int kMaxDevices = 64;
+    static std::atomic<size_t> attr_bytes[kMaxDevices];  // 0: never set
     if (lds > 160 * 1024) return hipErrorInvalidValue;  // (the planner keeps wide-palette 16-node clusters to four waves)
-    if (lds > attr_bytes.load(std::memory_order_acquire)) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+    if (lds > 64 * 1024 && lds > attr_bytes[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, CC, FW, SM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_bytes.store(lds, std::memory_order_release);
+        if (dev != kMaxDevices - 1) attr_bytes[dev].store(lds, std::memory_order_release);  // (an unknown device: set it every time)
     }
     hipLaunchKernelGGL((k_surfaces_fast<MM, NN, 1, CC, FW, SM>), dim3(grid_blocks), dim3(kWave * FW), lds, st, tiles,
                        n_tiles, na, sa, weather, nullptr, 0, nullptr, flags, nomass_iters, fa);
