@@ -962,12 +962,20 @@ int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state)
     const int64_t S = b->n_surf, Z = b->n_zones;
     double *pin = b->h_pin;
     const int64_t *slots = b->h_in_slots.data();
-    b->pool->run(4 * S, [&](int64_t i0, int64_t i1) {
-        for (int64_t i = i0; i < i1; i++) pin[i] = state[slots[i]];
-    });
+    // gathered by the thread pool and copied in pieces: the copy of one piece travels while the next is gathered
+    const int64_t total = 4 * S;
+    const int n_pieces = total >= (int64_t)1 << 20 ? 4 : 1;
+    for (int pc = 0; pc < n_pieces; pc++) {
+        const int64_t a = total * pc / n_pieces, e = total * (pc + 1) / n_pieces;
+        b->pool->run(e - a, [&](int64_t i0, int64_t i1) {
+            for (int64_t i = a + i0; i < a + i1; i++) pin[i] = state[slots[i]];
+        });
+        if (e > a)
+            HIP_TRY(hipMemcpyAsync(b->d_compact.p + a, pin + a, (size_t)(e - a) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
     for (int64_t z = 0; z < Z; z++) pin[4 * S + z] = state[b->h_zone_slot_h[z]];
-    if (4 * S + Z > 0)
-        HIP_TRY(hipMemcpyAsync(b->d_compact.p, pin, (size_t)(4 * S + Z) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (Z > 0)
+        HIP_TRY(hipMemcpyAsync(b->d_compact.p + 4 * S, pin + 4 * S, (size_t)Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
     launch_inputs_compact((int)S, (int)Z, b->d_compact.p, b->d_side_alpha.p, b->d_side_dyn.p, b->d_zone_T.p, b->sl,
                           b->direct_runs.empty() ? nullptr : b->d_state.p, b->stream);
     HIP_TRY(hipGetLastError());
