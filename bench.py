@@ -308,9 +308,18 @@ def main():
         batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True,
                           no_palette=args.no_palette, no_fusion=args.no_fusion)
         batch.upload_state(state)
+        try:  # (torch is plumbing here: its device-wide synchronize brackets the timed region as the contract words it)
+            import torch
+            torch_sync = torch.cuda.synchronize if torch.cuda.is_available() else None
+            if torch_sync:
+                torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        except Exception:
+            torch_sync = None
 
         def barrier():
-            batch.synchronize()
+            if torch_sync:
+                torch_sync()
+            batch.synchronize()  # the batch's own streams; reports device-side numerical flags
 
         run = batch.march_resident
 
