@@ -141,6 +141,7 @@ constexpr int kFusedMinSubsteps = 3;  // march calls of fewer sub-timesteps are 
 
 struct heat_batch {
     int device = 0;
+    int n_cu = 256;  // compute units of `device` (sizes the persistent grids and the fused launches' room)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // Independent surface classes run on side streams between a fork and a join event (captured into
@@ -635,7 +636,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     }
     if (unified)
         launch_surfaces_stream(b->d_ulist[ul].p, b->n_ulist[ul], b->na, b->gen_base, b->sa, b->d_weather.p, b->d_step.p,
-                               step_fixed, b->d_zone_T.p, b->d_flags.p, b->d_ucount.p + ul * b->ucount_stride, next_stream());
+                               step_fixed, b->d_zone_T.p, b->d_flags.p, b->d_ucount.p + ul * b->ucount_stride, b->n_cu, next_stream());
     // work of each class in node slots, to size the persistent grids
     double work[kNumFast], total_work = 0.0;
     for (int c = 0; c < kNumFast; c++) {
@@ -653,7 +654,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], kFastCAV[c], work[c] / total_work,
                              b->d_fast_tiles[c].p, nt[c], b->na,
                              b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
-                             b->d_nomass_iters.p + b->nm_count_base[c], next_stream());
+                             b->d_nomass_iters.p + b->nm_count_base[c], b->n_cu, next_stream());
     }
     unsigned long long *cnt = b->d_nomass_iters.p + b->nm_count_base[kNumFast];
     if (n_small_plain > 0)
@@ -726,12 +727,7 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
         }
         streamed_share = ns / std::max(ns + nf, 1.0);
     }
-    static const int n_cu = [] {
-        int dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        return cus;
-    }();
+    const int n_cu = b->n_cu;
     if (beside_exchange && b->d_fqueue.n == 0) HIP_TRY(b->d_fqueue.zeros(kNumFast * 4));
     for (int c = 0; c < kNumFast; c++)
         for (int g2 = 0; g2 < 4; g2++) {
@@ -835,6 +831,10 @@ int heat_batch_create_ex(const heat_batch_desc *desc, const heat_batch_options *
     b->use_graph = opt.use_graph != 0;
     b->fusion_on = opt.no_fusion != 1;
     rc = select_device(b);
+    if (!rc) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->n_cu = prop.multiProcessorCount;
+    }
     if (!rc) {
         if (opt.stream) {
             b->stream = reinterpret_cast<hipStream_t>(opt.stream);
@@ -1324,6 +1324,11 @@ int heat_batch_comm_init_ex(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES],
                             int32_t n_extra) {
     if (!b || !id || n_extra < 0 || (n_extra > 0 && !extra_shared)) return fail(HEAT_E_INVALID_ARG, "bad argument");
     if (b->comm) return fail(HEAT_E_INVALID_ARG, "the batch already has a communicator");
+    const int64_t Z = b->n_zones;
+    // (checked before anything collective happens: a bad list must not leave this rank outside a communicator the
+    // other ranks have already agreed on)
+    for (int32_t i = 0; i < n_extra; i++)
+        if (extra_shared[i] < 0 || extra_shared[i] >= Z) return fail(HEAT_E_SIZE, "shared zone %d out of range", extra_shared[i]);
     Rccl *r = rccl();
     if (!r) return fail(HEAT_E_COMM, "cannot load librccl.so.1: %s", rccl_error().c_str());
     int rc = select_device(b);
@@ -1331,28 +1336,40 @@ int heat_batch_comm_init_ex(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES],
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     RCCL_TRY(r, r->CommInitRank(&b->comm, b->n_ranks, u, b->rank));
-    // agree on the zones more than one rank touches: sum of the touched masks
-    const int64_t Z = b->n_zones;
-    std::vector<int32_t> mask(std::max<int64_t>(Z, 1), 0);
-    for (int64_t z = 0; z < Z; z++) mask[z] = b->h_touched[z];
-    DevBuf<int32_t> d_mask;
-    HIP_TRY(d_mask.upload(mask));
-    RCCL_TRY(r, r->AllReduce(d_mask.p, d_mask.p, mask.size(), ncclInt32, ncclSum, b->comm, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemcpy(mask.data(), d_mask.p, mask.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    std::vector<uint8_t> is_shared(std::max<int64_t>(Z, 1), 0);
-    for (int64_t z = 0; z < Z; z++) {
-        is_shared[z] = mask[z] >= 2;
-        // a zone no rank faces is finished by rank z % n_ranks (it still follows a0 / b0: model.rs:410-423)
-        b->h_owned[z] = (b->h_touched[z] || (mask[z] == 0 && z % b->n_ranks == b->rank)) ? 1 : 0;
+    // From here on a failure returns the batch to "sharded batch without a communicator": the communicator goes, so
+    // that a retry is possible and a march cannot take the no-exchange path on zones other ranks share.
+    const std::vector<uint8_t> owned_before = b->h_owned;
+    auto agree = [&]() -> int {
+        // agree on the zones more than one rank touches: sum of the touched masks
+        std::vector<int32_t> mask(std::max<int64_t>(Z, 1), 0);
+        for (int64_t z = 0; z < Z; z++) mask[z] = b->h_touched[z];
+        DevBuf<int32_t> d_mask;
+        HIP_TRY(d_mask.upload(mask));
+        RCCL_TRY(r, r->AllReduce(d_mask.p, d_mask.p, mask.size(), ncclInt32, ncclSum, b->comm, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipMemcpy(mask.data(), d_mask.p, mask.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> is_shared(std::max<int64_t>(Z, 1), 0);
+        for (int64_t z = 0; z < Z; z++) {
+            is_shared[z] = mask[z] >= 2;
+            // a zone no rank faces is finished by rank z % n_ranks (it still follows a0 / b0: model.rs:410-423)
+            b->h_owned[z] = (b->h_touched[z] || (mask[z] == 0 && z % b->n_ranks == b->rank)) ? 1 : 0;
+        }
+        for (int32_t i = 0; i < n_extra; i++) is_shared[extra_shared[i]] = 1;  // (tests, rehearsals of the exchange)
+        std::vector<int32_t> shared;
+        for (int64_t z = 0; z < Z; z++) if (is_shared[z]) shared.push_back((int32_t)z);
+        return heat_batch_set_shared_zones(b, shared.data(), (int32_t)shared.size());
+    };
+    rc = agree();
+    if (rc) {
+        const std::string why = heat::last_error();
+        (void)r->CommDestroy(b->comm);
+        b->comm = nullptr;
+        b->shared_set = false;
+        b->n_shared = 0;
+        b->h_owned = owned_before;
+        return fail(rc, "%s", why.c_str());
     }
-    for (int32_t i = 0; i < n_extra; i++) {  // zones the caller wants exchanged as well (tests, rehearsals)
-        if (extra_shared[i] < 0 || extra_shared[i] >= Z) return fail(HEAT_E_SIZE, "shared zone %d out of range", extra_shared[i]);
-        is_shared[extra_shared[i]] = 1;
-    }
-    std::vector<int32_t> shared;
-    for (int64_t z = 0; z < Z; z++) if (is_shared[z]) shared.push_back((int32_t)z);
-    return heat_batch_set_shared_zones(b, shared.data(), (int32_t)shared.size());
+    return HEAT_OK;
 }
 
 int32_t heat_batch_n_shared_zones(const heat_batch *b) { return (b && b->shared_set) ? b->n_shared : 0; }
@@ -1385,6 +1402,9 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
                                         "(a batch that shares no zone — heat_batch_set_shared_zones(b, NULL, 0) — needs neither)");
     int rc = heat_batch_set_weather(b, weather, n_sub, zone_a0, zone_b0);
     if (rc) return rc;
+    // A march of no sub-timestep (model.rs:369: the loop body never runs) is the head kernel and nothing else: the
+    // graph branch below must never capture or replay an empty graph.
+    if (n_sub == 0) return HEAT_OK;
     if (b->comm && exchange) {
         // Sharded sub-timestep, everything in order on the batch's stream (no cross-queue dependency anywhere):
         // this rank's surfaces -> zones only this rank touches finished, partial (a, b) of the shared zones ->
@@ -1502,8 +1522,8 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         // consecutive graph launches do. A call of another length re-captures; longer ones replay blocks.
         static const int per_graph_env = getenv("HEAT_AMD_GRAPH_SUBSTEPS") ? atoi(getenv("HEAT_AMD_GRAPH_SUBSTEPS")) : 0;
         // (a caller whose calls keep changing length gets the one-sub-timestep graph, which fits every length)
-        const int want = b->graph_recaptures > 8 ? 1 : (per_graph_env > 0 ? std::min(per_graph_env, n_sub) : std::min(n_sub, 32));
-        if (!b->graph_exec || b->graph_fused != fused || (b->graph_subs != want && n_sub % b->graph_subs != 0)) {
+        const int want = std::max(1, b->graph_recaptures > 8 ? 1 : (per_graph_env > 0 ? std::min(per_graph_env, n_sub) : std::min(n_sub, 32)));
+        if (!b->graph_exec || b->graph_fused != fused || b->graph_subs <= 0 || (b->graph_subs != want && n_sub % b->graph_subs != 0)) {
             if (b->graph_exec && b->graph_fused == fused) b->graph_recaptures++;
             if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
             if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }

@@ -2,6 +2,7 @@
 // the pinned staging buffers of heat_batch_march (the device copies run meanwhile). Host-only.
 #pragma once
 #include <condition_variable>
+#include <cstdint>
 #include <functional>
 #include <mutex>
 #include <thread>

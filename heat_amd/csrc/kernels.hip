@@ -1814,16 +1814,11 @@ static inline size_t pal_lds_bytes(const NodeArrays &na) { return (size_t)4 * kW
 void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
                           const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
-                          const double *zone_T, int *flags, unsigned long long *nomass_iters, hipStream_t st) {
+                          const double *zone_T, int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st) {
     if (n_tiles <= 0) return;
     // persistent grid: as many 4-wave blocks as the chip holds at this kernel's occupancy (waves per SIMD by
-    // VGPR count: M = 4 -> 5, M = 8 -> 3, M = 16 -> 2), capped by the number of tiles
-    static const int n_cu = [] {
-        int dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        return cus;
-    }();
+    // VGPR count: M = 4 -> 5, M = 8 -> 3, M = 16 -> 2), capped by the number of tiles; n_cu: compute units of the
+    // batch's device
     static const int tune = getenv("HEAT_AMD_PERSIST") ? atoi(getenv("HEAT_AMD_PERSIST")) : 1;
     const int blocks_per_cu = (M == 4 ? 5 : (M == 8 ? 3 : 2)) * tune;
     const int full_grid = blocks_for_waves(n_tiles);
@@ -1854,14 +1849,8 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
 // grid: persistent, two 4-wave blocks per compute unit (256 registers per lane), capped by the tile count.
 void launch_surfaces_stream(const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
-                            int *flags, unsigned long long *nomass_iters, hipStream_t st) {
+                            int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st) {
     if (n_tiles <= 0) return;
-    static const int n_cu = [] {
-        int dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        return cus;
-    }();
     static const int per_cu = getenv("HEAT_AMD_STREAM_BLOCKS") ? atoi(getenv("HEAT_AMD_STREAM_BLOCKS")) : 2;
     const int grid = std::min(blocks_for_waves(n_tiles), n_cu * std::max(per_cu, 1));
     hipLaunchKernelGGL(k_surfaces_stream, dim3(grid), dim3(256), pal_lds_bytes(na), st, tiles, n_tiles, na, gen_base, sa, weather, step_ptr,

@@ -239,6 +239,32 @@ def test_march_equals_resident_march_plus_download(oracle):
     assert np.array_equal(a, b_)  # same kernels, same order: bitwise equal
 
 
+def test_zero_length_march_is_a_no_op_also_as_the_first_call_of_a_graph_batch(oracle):
+    """ThermalModel::march with dt_subdivisions == 0 runs its loop body never (model.rs:369): the call returns at
+    once, leaves the state alone, and a graph batch must neither capture an empty graph nor divide by its length."""
+    md, st = mdl.ragged_mixed(300, Z=3, dt=45.0, seed=21)
+    w = mdl.weather_series(6, 45.0)
+    ref = st.copy()
+    rc, _ = oracle.OracleModel(md).march(ref, w)
+    assert rc == 0
+    for kw in (dict(use_graph=True), dict(use_graph=True, no_fusion=True), dict()):
+        got = st.copy()
+        with HeatBatch(md, **kw) as b:
+            b.upload_state(got)
+            b.march_resident(w[:0])          # first call: nothing captured yet
+            b.synchronize()
+            before = got.copy()
+            b.download_state(before)
+            assert np.array_equal(before[mdl.node_slots(md)], st[mdl.node_slots(md)])
+            b.march_resident(w[:4])
+            b.march_resident(w[:0])          # between two real calls: the captured graph's length stays valid
+            b.march_resident(w[4:])
+            b.synchronize()
+            b.download_state(got)
+            b.march(got.copy(), w[:0])       # the drop-in call of no sub-timestep
+        assert_state_close(md, ref, got)
+
+
 def test_split_phase_steps_equal_fused_march(oracle):
     md, st = mdl.ragged_mixed(400, Z=4, dt=45.0, seed=5)
     w = mdl.weather_series(6, 45.0)

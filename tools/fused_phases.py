@@ -6,7 +6,8 @@ final write-back; in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz ov
 import os, sys, types, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["HEAT_AMD_LIB"] = os.path.join(ROOT, "heat_amd", "lib", "libheat_amd_stamps.so")
+from heat_amd import build as _hb
+os.environ["HEAT_AMD_LIB"] = _hb.build_stamps()  # (built on demand: __graft_entry__.build() treats it as optional)
 import numpy as np
 import bench
 from heat_amd import HeatBatch, modeldict as mdl, binding
