@@ -258,11 +258,13 @@ int32_t heat_batch_n_shared_zones(const heat_batch *b);
  * Cluster-resident march (on by default). ThermalModel::march runs its dt_subdivisions sub-timesteps back to back
  * and nothing outside reads the state in between (model.rs:369-424), and surfaces exchange heat only through the
  * zones they face (model.rs:556-590). So the batch is cut into zone-connected clusters; a cluster whose surfaces
- * are all palette-form fast-path walls without gas cavities and that fits one workgroup (8 wavefronts, 32 zones)
- * is marched for ALL n_sub sub-timesteps of a heat_batch_march[_resident] call by one workgroup: node temperatures
- * stay in registers, the zone balance is summed in LDS in the reference's order, and only the final temperatures,
- * coefficients and flows are written. Everything else is streamed one sub-timestep per launch beside it. Results are
- * the same as the streamed march's to the last bit of the zone sums' order (tested at 1e-9 against the oracle).
+ * are all palette-form fast-path walls (gas cavities between massive nodes allowed with 4 or 8 nodes per lane) or small
+ * all-no-mass surfaces, and for which the planner's cost model expects a gain, is marched for ALL n_sub sub-timesteps
+ * of a heat_batch_march[_resident] call resident on the chip: node temperatures stay in registers, the zone balance is
+ * summed on the chip, and only the final temperatures, coefficients and flows are written. Everything else is streamed
+ * one sub-timestep per launch. The zone sums (here and in the streamed k_zones) are lane-strided partial sums followed
+ * by a fixed reduction tree: deterministic run to run, but NOT the sequential surface order of model.rs:562-585 — the
+ * results differ from a sequential sum by rounding (~1e-16 relative; everything is tested at 1e-9 against the oracle).
  * March calls of fewer than three sub-timesteps are streamed as well (the fused launch only pays off from three on).
  * heat_batch_set_fusion(b, 0) streams everything (used to measure the per-sub-timestep kernel on its own). */
 int heat_batch_set_fusion(heat_batch *b, int32_t enabled);

@@ -1,4 +1,6 @@
-//! FFI declarations of include/heat_amd.h (ABI version 1). Unverified: not compiled in this repository.
+//! FFI declarations of include/heat_amd.h (ABI version 1) — `src/gpu_ffi.rs` of the `heat` crate, feature `gpu`.
+//! Unverified: not compiled in this repository. Struct layouts are checked against the C header by
+//! tests/test_abi_symbols.py (ctypes mirrors of the same structs vs gcc's offsetof).
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)] pub struct HeatCavity { pub thickness: f64, pub height: f64, pub angle: f64,
