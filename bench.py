@@ -4,8 +4,7 @@
 A *step* is one sub-timestep of ThermalModel::march (reference src/model.rs:369-424) over the whole
 model: iterate_surfaces for every surface + the zone update. The default workload is the north_star
 headline of BASELINE.json — 1 000 000 all-massive surfaces x 32 nodes, RK4 + convection / long-wave /
-solar boundary updates, zones of 100 surfaces; `--config 2 | 3 | 5 | partitions` selects the other
-BASELINE configs. State is resident in HBM when the timed region starts.
+solar boundary updates, zones of 100 surfaces. State is resident in HBM when the timed region starts.
 
 The K timed steps are issued as march calls of --substeps-per-march sub-timesteps each (default 20: a
 15-minute model timestep at dt = 45 s), as ThermalModel::march runs its dt_subdivisions sub-timesteps
@@ -18,16 +17,26 @@ every sub-timestep through HBM instead, and a second, shorter leg always measure
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+With --config headline (the default) and one GPU the run goes on, after the headline, through the other BASELINE.json
+configs as short legs of their own — config 3 (1 M ragged mixed walls), config 5 (glazing + cavities), config 2
+(10 000 identical walls) and `partitions` (buildings of rooms joined by interior walls) — and attaches each as
+`"configs": {"3": {value, ms_per_step, roofline{...}, cpu_baseline{...}}, ...}` to the SAME JSON line
+(--no-configs skips them; `--config 3` etc. runs one of them as the main leg).
+
 N > 1 (BASELINE config 4) shards the SAME model over the ranks ("scaling": "strong"): heat_partition cuts it
-along its zone-connected clusters, so that no zone is shared and no collective is issued (the headline; config 3's
-ring of zones is one cluster and is cut by surface ranges — its cut zones are exchanged with an RCCL all-gather per
-sub-timestep). `--scaling weak` gives every rank a model of its own with zones shared across the rank boundaries.
+along its zone-connected clusters, so that no zone is shared and no collective is issued (the headline). A second,
+short leg then runs config 3, whose ring of zones is ONE cluster: it is cut by surface ranges and its cut zones are
+exchanged with an RCCL all-gather per sub-timestep on the library's own communicator — `"exchange_leg"` reports
+n_shared_zones, collective, comm_ranks (and collective_fallback when the native communicator could not be had on
+every rank). `--scaling weak` gives every rank a model of its own with zones shared across the rank boundaries.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline            the dominant kernel against the resource that bounds it: "hbm" for a streamed march
-                      (algorithmic bytes / kernel time, HIP events on the kernel's stream, against 8 TB/s), "valu_issue"
-                      for a cluster-resident march (VALU wave-instructions per second, instruction count from the
-                      committed SQ counters, against SIMDs x clock / 4);
+  roofline            the dominant kernel against the resource that bounds it. Streamed march: "hbm" — algorithmic
+                      bytes / kernel time (HIP events on the kernel's stream) against 8 TB/s. Cluster-resident march:
+                      "valu_f64" — ALGORITHMIC f64 flops (40 per node-update) / kernel time against
+                      the f64 vector peak, 78.6 TFLOP/s; its `issue` sub-object keeps the issue-slot view (measured
+                      instruction counts by class from the committed PMC passes x cycles per class) and is nulled,
+                      with "counters_stale": true, when the committed counters were taken on other kernel sources;
   roofline_streaming  the streamed kernel's own line whenever the main run was cluster-resident;
   cpu_baseline        the CPU oracle (oracle/, a C port of the reference path) timed on this box's host cores on a
                       bounded sample of the same workload (rank 0, N = 1 only);
@@ -35,10 +44,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
                       PCIe-inclusive rate, never `value`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+import traceback
 
 import numpy as np
 
@@ -47,10 +58,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles each (16 lanes wide), 2.4 GHz peak engine clock
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # 1e9 wave-instructions per second
+# f64 vector peak: 256 CUs x 4 SIMDs x 16 f64 lanes per cycle x 2 flops (FMA) x 2.4 GHz (a wave64 f64 instruction
+# issues over 4 cycles; MI355X_MICROARCH.md "Wave scheduling", 32-bit VALU: 2 cycles)
+F64_PEAK_TFLOPS = 256 * 4 * 16 * 2 * 2.4e9 / 1e12
+SIMD_CYCLES_PER_SEC = 256 * 4 * 2.4e9
+VALU_CYCLES_F64, VALU_CYCLES_OTHER = 4.0, 2.0
+# ~ 4 (5 + 2) + 12 = 40 flops per node-update of the RK4 stencil (boundary work is O(1) per surface)
+ALGORITHMIC_FLOPS_PER_NODE_UPDATE = 40.0
 
 CONFIGS = ("headline", "2", "3", "5", "partitions")
+KERNEL_SOURCES = ("heat_amd/csrc/kernels.hip", "heat_amd/csrc/device_math.hpp", "heat_amd/csrc/layout.hpp")
+
+
+def kernel_source_hash():
+    """sha256 over the device sources: committed counters are only good for the kernels they were measured on
+    (tools/make_counters.py stamps the same hash into profiles/*_counters.json)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def build_weak_shard(S, n, zones_per_gpu, rank, world, dt, seed):
@@ -107,7 +134,7 @@ def cpu_baseline(md_full, state_full, dt, target_seconds=12.0):
     md = mdl.subset(md_full, np.arange(S_cpu))
     state = state_full.copy()
     nodes = int(md["node_offset"][-1])
-    steps = 10
+    steps = 10 if target_seconds >= 8 else 4
     m = orc.OracleModel(md)
     w = mdl.weather_series(steps, dt)
     t0 = time.perf_counter()
@@ -143,9 +170,11 @@ def cpu_baseline(md_full, state_full, dt, target_seconds=12.0):
 
 def committed_counters(config, surfaces, nodes_total, mode, substeps=1):
     """Counters of the surface kernel from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot run
-    the profiler on itself): the newest profiles/*_counters.json whose workload matches. Returns (dict, source)."""
-    best = (None, None)
+    the profiler on itself): the newest profiles/*_counters.json whose workload matches. Returns (dict, source, stale):
+    stale = the file carries no hash of the kernel sources, or another one than the sources this run was built from."""
+    best = (None, None, None)
     pdir = os.path.join(ROOT, "profiles")
+    now = kernel_source_hash()
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if not f.endswith("_counters.json"):
             continue
@@ -160,7 +189,7 @@ def committed_counters(config, surfaces, nodes_total, mode, substeps=1):
             continue
         if mode == "fused" and wl.get("substeps_per_launch") != substeps:
             continue
-        best = (j, "profiles/" + f)
+        best = (j, "profiles/" + f, j.get("kernel_sources_sha256") != now)
     return best
 
 
@@ -170,17 +199,74 @@ def march_in_calls(march, weather, per_call):
         march(weather[i:i + per_call])
 
 
-def hbm_roofline(ab, surf_us, substep_us, n, counters, src, kernel):
+def hbm_roofline(ab, surf_us, substep_us, n, counters, src, stale, kernel):
     achieved = ab / (surf_us * 1e-6) / 1e9
-    traffic = counters.get("hbm_traffic_bytes_per_launch") if counters else None
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": kernel,
-            "algorithmic_bytes_per_launch": ab, "kernel_us": surf_us, "substep_us": substep_us,
-            "frac_whole_sub_timestep": ab / (substep_us * 1e-6) / 1e9 / HBM_PEAK_GBS if substep_us else None,
-            "samples": n}
+    traffic = counters.get("hbm_traffic_bytes_per_launch") if (counters and not stale) else None
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": src, "kernel": kernel,
+         "algorithmic_bytes_per_launch": ab, "kernel_us": surf_us, "substep_us": substep_us,
+         "frac_whole_sub_timestep": ab / (substep_us * 1e-6) / 1e9 / HBM_PEAK_GBS if substep_us else None,
+         "samples": n}
+    if counters:
+        r["counters_stale"] = bool(stale)
+        if not stale:
+            for k in ("SQ_WAIT_ANY_frac_of_wave_cycles", "SQ_ACTIVE_INST_VALU_frac_of_wave_cycles", "valu_insts_per_launch"):
+                if k in counters:
+                    r[k] = counters[k]
+    return r
 
 
-def streaming_leg(md, state, args, dt, steps=60, warmup=10):
+def fused_roofline(nodes_local, n_nodes_counted, P, surf_us, substep_us, n_samples, algorithmic_bytes, counters, src, stale):
+    """Cluster-resident march: the state is re-used on chip (1 GB of HBM traffic for 23.5 GB of algorithmic bytes at
+    20 sub-timesteps), so neither HBM nor MFMA bounds it: the line is the ALGORITHMIC f64 work against the f64 vector
+    peak. `issue` is the instruction-issue view from the committed counters of this workload (per-class counts)."""
+    useful = ALGORITHMIC_FLOPS_PER_NODE_UPDATE * nodes_local / (surf_us * 1e-6) / 1e12
+    rl = {"bound": "valu_f64", "achieved": useful, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": useful / F64_PEAK_TFLOPS, "useful_f64_frac": useful / F64_PEAK_TFLOPS,
+          "algorithmic_flops_per_node_update": ALGORITHMIC_FLOPS_PER_NODE_UPDATE,
+          "peak_note": "256 CUs x 4 SIMDs x 16 f64 lanes x 2 flops x 2.4 GHz",
+          "kernel": "k_surfaces_fast<M,...,FUSED> (cluster-resident march: %d sub-timesteps of iterate_surfaces + zone "
+                    "balance per launch, node temperatures in registers)" % P,
+          "sub_timesteps_per_launch": P, "kernel_us": surf_us * P, "kernel_us_per_sub_timestep": surf_us,
+          "substep_us": substep_us, "samples": n_samples, "traffic": None, "counters_source": src,
+          "counters_stale": bool(stale) if counters else None,
+          "equivalent_streaming_gbs": algorithmic_bytes / (surf_us * 1e-6) / 1e9,
+          "equivalent_streaming_note": "algorithmic (streaming) bytes of the same sub-timesteps / kernel time: what a "
+                                       "streamed march would have to sustain; not a roofline fraction"}
+    if counters and not stale:
+        scale = nodes_local / counters["workload"]["nodes_total"]  # (a rank of a sharded run launches its share)
+        per_sub = scale / counters["workload"]["substeps_per_launch"]
+        valu = counters["valu_insts_per_launch"] * per_sub
+        issue = {"valu_insts_per_sub_timestep": valu}
+        cl = counters.get("counters_per_launch", {})
+        f64 = [cl.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+        if all(v is not None for v in f64):
+            n64 = sum(f64) * per_sub
+            cyc = n64 * VALU_CYCLES_F64 + max(valu - n64, 0.0) * VALU_CYCLES_OTHER
+            issue.update({"f64_insts_per_sub_timestep": n64, "issue_cycles_per_sub_timestep": cyc,
+                          "frac": cyc / (surf_us * 1e-6) / SIMD_CYCLES_PER_SEC,
+                          "note": "measured wave-instructions by class (SQ_INSTS_VALU_*_F64 at 4 cycles, every other "
+                                  "VALU instruction at 2) / (1024 SIMDs x 2.4 GHz x kernel time)"})
+            # the f64 flops the kernel really issued (adds and multiplies 1, FMAs 2, per lane of 64)
+            meas = (f64[0] + f64[1] + 2 * f64[2]) * 64 * per_sub / (surf_us * 1e-6) / 1e12
+            rl["measured_f64_tflops"] = meas
+            rl["measured_f64_frac"] = meas / F64_PEAK_TFLOPS
+        else:
+            cyc = valu * VALU_CYCLES_F64
+            issue.update({"issue_cycles_per_sub_timestep": cyc, "frac": cyc / (surf_us * 1e-6) / SIMD_CYCLES_PER_SEC,
+                          "note": "no per-class counts in the committed file: every VALU instruction booked at 4 cycles "
+                                  "(an upper bound of the occupancy)"})
+        rl["issue"] = issue
+        t = counters.get("hbm_traffic_bytes_per_launch")
+        if t:
+            rl["traffic"] = t * scale
+            rl["hbm_gbs_measured_traffic"] = rl["traffic"] / (surf_us * P * 1e-6) / 1e9
+    else:
+        rl["issue"] = None
+    return rl
+
+
+def streaming_leg(md, state, args, config, dt, steps=60, warmup=10):
     """The per-sub-timestep kernels on their own: a batch planned without the cluster-resident march, HIP events
     around every sub-timestep."""
     from heat_amd import HeatBatch, modeldict as mdl
@@ -196,12 +282,209 @@ def streaming_leg(md, state, args, dt, steps=60, warmup=10):
         surf_us, substep_us, n = b.get_timing()
         ab = b.algorithmic_bytes
         counts = b.class_counts()
-    counters, src = committed_counters(args.config, int(md["n_surfaces"]), int(md["node_offset"][-1]), "streamed")
-    r = hbm_roofline(ab, surf_us, substep_us, n, counters, src,
+    counters, src, stale = committed_counters(config, int(md["n_surfaces"]), int(md["node_offset"][-1]), "streamed")
+    r = hbm_roofline(ab, surf_us, substep_us, n, counters, src, stale,
                      "streamed march: iterate_surfaces, one sub-timestep per launch, state streamed through HBM")
     r["node_updates_per_sec"] = int(md["node_offset"][-1]) * steps / el
     r["kernel_classes[M4,M8,M16,small,general]"] = counts
     return r
+
+
+def torch_device_sync(local_rank):
+    """(torch is plumbing here: its device-wide synchronize brackets the timed region as the contract words it)"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+            return torch.cuda.synchronize
+    except Exception:
+        pass
+    return None
+
+
+def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
+    """One workload on one GPU: W untimed + K timed sub-timesteps as march calls of P, the kernel's roofline from HIP
+    events inside the timed region, the CPU baseline on a bounded sample. main: the headline's extras too."""
+    from heat_amd import HeatBatch, modeldict as mdl
+    md, state, workload = build_config(config, args, 45.0, seed)
+    dt = float(md["dt"])
+    n_nodes = int(md["node_offset"][-1])
+    batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True,
+                      no_palette=args.no_palette, no_fusion=args.no_fusion)
+    try:
+        batch.upload_state(state)
+        torch_sync = torch_device_sync(local_rank)
+
+        def barrier():
+            if torch_sync:
+                torch_sync()
+            batch.synchronize()  # the batch's own streams; reports device-side numerical flags
+
+        if W > 0:
+            march_in_calls(batch.march_resident, mdl.weather_series(W, dt), P)
+        barrier()
+        # HIP events around the kernels inside the timed region: every call of a cluster-resident march (two events per
+        # launch); of a streamed march ONE call in three, or the first call only when the region has fewer (three events
+        # per sub-timestep, issued eagerly — the other calls replay the hipGraph as an untimed march does)
+        n_local = batch.n_surfaces_in_batch
+        fused = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if n_local <= 8192 else 3)
+        batch.set_timing(0 if args.no_timing else (1 if fused else max(3, -(-K // P))))
+        weather_k = mdl.weather_series(K, dt, t0=dt * W)
+        t0 = time.perf_counter()
+        march_in_calls(batch.march_resident, weather_k, P)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        surf_us, substep_us, n_samples = batch.get_timing()
+        batch.set_timing(False)
+        ab = batch.algorithmic_bytes
+        counts = batch.class_counts()
+        n_fused = batch.n_fused_surfaces if not args.no_fusion else 0
+        res = {"value": n_nodes * K / elapsed, "unit": "node-updates/s", "steps": K, "warmup": W,
+               "ms_per_step": elapsed / K * 1e3, "sub_timesteps_per_sec": K / elapsed,
+               "config": {"workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
+                          "config": config, "surfaces": int(md["n_surfaces"]), "nodes": n_nodes,
+                          "zones": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
+                          "surfaces_on_rank0": n_local, "kernel_classes_rank0[M4,M8,M16,small,general]": counts,
+                          "surfaces_in_cluster_resident_march_rank0": n_fused, "n_shared_zones": 0,
+                          "parallelism": "single GPU"}}
+        if n_samples > 0 and fused:
+            counters, src, stale = committed_counters(config, int(md["n_surfaces"]), n_nodes, "fused", P)
+            res["roofline"] = fused_roofline(batch.n_nodes, n_nodes, P, surf_us, substep_us, n_samples, ab, counters, src, stale)
+        elif n_samples > 0:
+            counters, src, stale = committed_counters(config, int(md["n_surfaces"]), n_nodes, "streamed")
+            res["roofline"] = hbm_roofline(ab, surf_us, substep_us, n_samples, counters, src, stale,
+                                           "streamed march: k_surfaces_stream / k_surfaces_fast / k_surfaces_small "
+                                           "(iterate_surfaces: RK4 stencil + boundary updates, one sub-timestep per launch)")
+            # the same bytes over the wall-clock time of a step of the timed region (graph replay, launches and all)
+            res["roofline"]["frac_wall_clock_step"] = ab / (elapsed / K) / 1e9 / HBM_PEAK_GBS
+            if config == "5":
+                res["roofline"]["bound_note"] = (
+                    "config 5 moves 0.1 GB per sub-timestep: HBM is not what bounds it. Its time is the no-mass "
+                    "fixed-point loop of the glazing (Cavity::u_value + Nusselt correlations re-evaluated every pass, "
+                    "surface.rs:814): dependent f64 transcendental chains at 2 wavefronts per SIMD — a latency bound; "
+                    "the hbm line is kept for the contract's shape, SQ_WAIT / VALU-active fractions come from the "
+                    "committed counters when they are fresh")
+        if main and not args.no_extras:
+            # the drop-in call on a caller-owned host state (PCIe-inclusive; never `value`)
+            st = state.copy()
+            wcall = mdl.weather_series(P, dt)
+            batch.march(st, wcall)
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                batch.march(st, wcall)
+            tc = (time.perf_counter() - t0) / reps
+            res["caller_owned"] = {"value": n_nodes * P / tc, "unit": "node-updates/s", "ms_per_call": tc * 1e3,
+                                   "sub_timesteps_per_call": P, "state_megabytes": st.nbytes / 1e6,
+                                   "note": "heat_batch_march: inputs up, march, outputs down, caller's pageable numpy array"}
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                batch.march(st, wcall, outputs=HeatBatch.OUT_SCALARS | HeatBatch.OUT_ZONES)
+            tc = (time.perf_counter() - t0) / reps
+            res["caller_owned"]["scalars_and_zones_only"] = {
+                "value": n_nodes * P / tc, "ms_per_call": tc * 1e3,
+                "note": "heat_batch_march_ex(HEAT_OUT_SURFACE_SCALARS | HEAT_OUT_ZONE_TEMPERATURES): what the Rust shim "
+                        "asks for every call; node temperatures on demand"}
+            # how the sub-timesteps per march call change the picture (the reference's config 1 runs 2 per call)
+            sens = {}
+            for p in (2, 5, 20):
+                wv = mdl.weather_series(p, dt)
+                calls = max(2, 40 // p)
+                batch.march_resident(wv)
+                batch.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    batch.march_resident(wv)
+                batch.synchronize()
+                sens[str(p)] = n_nodes * p * calls / (time.perf_counter() - t0)
+            res["value_by_substeps_per_march"] = sens
+    finally:
+        batch.close()
+    if fused and not args.no_streaming_leg:
+        res["roofline_streaming"] = streaming_leg(md, state, args, config, dt, steps=60 if main else 20)
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(md, state, dt, cpu_seconds)
+    return res
+
+
+def sharded_leg(config, args, K, W, P, seed, rank, world, local_rank, weak):
+    """One workload on `world` ranks (one process per GPU). Returns the rank-0 view; every rank must call it."""
+    import torch
+    import torch.distributed as dist
+    from heat_amd import modeldict as mdl
+    from heat_amd.sharded import ShardedMarch, partition_model
+    if weak:
+        md, state = build_weak_shard(args.surfaces, args.nodes, max(1, args.surfaces // 100), rank, world, 45.0, seed)
+        workload = ("north_star headline, weak scaling: %d all-massive surfaces x %d nodes PER GPU, zones of 100 walls "
+                    "offset by half a zone against the rank boundaries, dt = 45 s" % (args.surfaces, args.nodes))
+    else:
+        md, state, workload = build_config(config, args, 45.0, seed)
+    dt = float(md["dt"])
+    n_nodes_model = int(md["node_offset"][-1])
+    forced = None
+    if args.force_shared_zones > 0:
+        forced = np.unique(np.linspace(0, int(md["n_zones"]) - 1, args.force_shared_zones).astype(np.int32))
+    ranks = n_shared_partition = None
+    if not weak:
+        # every rank cuts the same model the same way (host-only, deterministic): whole clusters per rank
+        ranks, n_shared_partition = partition_model(md, world)
+    dev = local_rank % max(torch.cuda.device_count(), 1)
+    sm = ShardedMarch(md, rank, world, device_index=dev, collective=args.collective, force_shared=forced,
+                      rank_of_surface=ranks, n_shared_in_partition=n_shared_partition,
+                      nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=args.no_fusion,
+                      use_graph=True)
+    try:
+        batch = sm.batch
+        batch.upload_state(state)
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+            batch.synchronize()  # reports device-side numerical flags
+
+        if W > 0:
+            march_in_calls(sm.march_resident, mdl.weather_series(W, dt), P)
+        barrier()
+        n_local = batch.n_surfaces_in_batch
+        fused = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if n_local <= 8192 else 3)
+        batch.set_timing(0 if args.no_timing else (1 if fused else max(3, -(-K // P))))
+        t0 = time.perf_counter()
+        march_in_calls(sm.march_resident, mdl.weather_series(K, dt, t0=dt * W), P)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        surf_us, substep_us, n_samples = batch.get_timing()
+        batch.set_timing(False)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        total_nodes = n_nodes_model * (world if weak else 1)
+        n_shared = batch.n_shared_zones
+        how = {"native": "library-owned RCCL communicator, all-gather in the batch's one stream",
+               "torch": "torch.distributed.all_gather_into_tensor", "none": "no collective issued"}[sm.collective]
+        res = {"value": total_nodes * K / elapsed, "unit": "node-updates/s", "steps": K, "warmup": W,
+               "ms_per_step": elapsed / K * 1e3, "sub_timesteps_per_sec": K / elapsed,
+               "n_shared_zones": n_shared, "collective": sm.collective, "comm_ranks": sm.comm_ranks,
+               "collective_fallback": sm.collective_fallback,
+               "config": {"workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
+                          "config": config, "surfaces": int(md["n_surfaces"]) * (world if weak else 1),
+                          "nodes": total_nodes, "zones": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
+                          "surfaces_on_rank0": n_local,
+                          "kernel_classes_rank0[M4,M8,M16,small,general]": batch.class_counts(),
+                          "surfaces_in_cluster_resident_march_rank0": batch.n_fused_surfaces if not args.no_fusion else 0,
+                          "n_shared_zones": n_shared,
+                          "parallelism": "surfaces sharded %d-way %s, zones replicated; %d zones shared between ranks (%s)" % (
+                              world, "by rank-local models" if weak else "along the zone-connected clusters (heat_partition)",
+                              n_shared, how)}}
+        ab = batch.algorithmic_bytes
+        if n_samples > 0 and fused:
+            counters, src, stale = committed_counters(config, int(md["n_surfaces"]), n_nodes_model, "fused", P)
+            res["roofline"] = fused_roofline(batch.n_nodes, n_nodes_model, P, surf_us, substep_us, n_samples, ab, counters, src, stale)
+        elif n_samples > 0:
+            res["roofline"] = hbm_roofline(ab, surf_us, substep_us, n_samples, None, None, None,
+                                           "streamed march of rank 0's shard (iterate_surfaces, one sub-timestep per launch)")
+        return res
+    finally:
+        sm.close()
 
 
 def main():
@@ -210,7 +493,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=CONFIGS, default="headline",
-                    help="workload: the north_star headline (default) or a BASELINE.json config")
+                    help="workload of the main leg: the north_star headline (default) or a BASELINE.json config")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline only: skip the legs of BASELINE configs 3, 5, 2 and partitions")
+    ap.add_argument("--config-steps", type=int, default=60, help="timed sub-timesteps of each of those legs")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: shard the same model (BASELINE config 4; default) or give every rank its own")
     ap.add_argument("--surfaces", type=int, default=1_000_000, help="surfaces of the model (weak scaling: per GPU)")
@@ -230,6 +516,7 @@ def main():
                     help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
     ap.add_argument("--force-shared-zones", type=int, default=0,
                     help="single-GPU rehearsal of the exchange: declare this many zones shared (implies --force-sharded)")
+    ap.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the config-3 leg that exercises the collective")
     ap.add_argument("--collective", choices=("native", "torch"), default="native",
                     help="sharded: library-owned RCCL communicator, all in one stream (default), or "
                          "torch.distributed.all_gather_into_tensor between the split-phase calls")
@@ -247,226 +534,63 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     K, W = args.steps, args.warmup
-    dt = 45.0
-    seed = 20260401
-    weak = args.scaling == "weak" and (world > 1 or args.force_sharded or args.force_shared_zones > 0)
-
-    from heat_amd import HeatBatch, modeldict as mdl
-    if weak:
-        if args.config != "headline":
-            raise SystemExit("--scaling weak exists for the headline workload only")
-        md, state = build_weak_shard(args.surfaces, args.nodes, max(1, args.surfaces // 100), rank, world, dt, seed)
-        workload = ("north_star headline, weak scaling: %d all-massive surfaces x %d nodes PER GPU, zones of 100 walls "
-                    "offset by half a zone against the rank boundaries, dt = %g s" % (args.surfaces, args.nodes, dt))
-    else:
-        md, state, workload = build_config(args.config, args, dt, seed)
-    dt = float(md["dt"])
-    n_nodes_model = int(md["node_offset"][-1])
-    weather_w = mdl.weather_series(max(W, 1), dt)
-    weather_k = mdl.weather_series(K, dt, t0=dt * W)
-
-    sharded = world > 1 or args.force_sharded or args.force_shared_zones > 0
-    n_shared_partition = None
-    sm = None
-    if sharded:
-        import torch
-        import torch.distributed as dist
-        from heat_amd.sharded import ShardedMarch, partition_model
-        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            # (HEAT_AMD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU, where
-            # RCCL refuses a second rank on the same device; only barriers and the timing reduction go through it)
-            backend = os.environ.get("HEAT_AMD_BENCH_BACKEND", "nccl")
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
-        forced = None
-        if args.force_shared_zones > 0:
-            forced = np.unique(np.linspace(0, int(md["n_zones"]) - 1, args.force_shared_zones).astype(np.int32))
-        ranks = None
-        if not weak:
-            # every rank cuts the same model the same way (host-only, deterministic): whole clusters per rank
-            ranks, n_shared_partition = partition_model(md, world)
-        sm = ShardedMarch(md, rank, world, device_index=local_rank % max(torch.cuda.device_count(), 1),
-                          collective=args.collective, force_shared=forced,
-                          rank_of_surface=ranks, n_shared_in_partition=n_shared_partition,
-                          nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=args.no_fusion,
-                          use_graph=True)
-        batch = sm.batch
-        batch.upload_state(state)
-
-        def barrier():
-            dist.barrier()
-            torch.cuda.synchronize()
-            batch.synchronize()  # reports device-side numerical flags
-
-        run = sm.march_resident
-    else:
-        batch = HeatBatch(md, device=local_rank, nodes_per_lane=args.nodes_per_lane, use_graph=True,
-                          no_palette=args.no_palette, no_fusion=args.no_fusion)
-        batch.upload_state(state)
-        try:  # (torch is plumbing here: its device-wide synchronize brackets the timed region as the contract words it)
-            import torch
-            torch_sync = torch.cuda.synchronize if torch.cuda.is_available() else None
-            if torch_sync:
-                torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        except Exception:
-            torch_sync = None
-
-        def barrier():
-            if torch_sync:
-                torch_sync()
-            batch.synchronize()  # the batch's own streams; reports device-side numerical flags
-
-        run = batch.march_resident
-
     P = max(1, args.substeps_per_march)
-    if W > 0:
-        march_in_calls(run, weather_w[:W], P)
-    barrier()
-    # HIP events around the kernels inside the timed region: every call of a cluster-resident march (two events per
-    # launch); of a streamed march ONE call in three, or the first call only when the region has fewer (three events per
-    # sub-timestep, issued eagerly — the other calls replay the hipGraph as an untimed march does)
-    will_fuse = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if batch.n_surfaces_in_batch <= 8192 else 3)
-    batch.set_timing(0 if args.no_timing else (1 if will_fuse else max(3, -(-K // P))))
-    t0 = time.perf_counter()
-    march_in_calls(run, weather_k, P)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    surf_us, substep_us, n_samples = batch.get_timing()
-    batch.set_timing(False)
+    seed = 20260401
+    sharded = world > 1 or args.force_sharded or args.force_shared_zones > 0
+    weak = args.scaling == "weak" and sharded
+    if weak and args.config != "headline":
+        raise SystemExit("--scaling weak exists for the headline workload only")
 
-    if sharded:
-        import torch
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    algorithmic_bytes = batch.algorithmic_bytes      # of this rank's batch
-    counts = batch.class_counts()
-    n_fused = batch.n_fused_surfaces if not args.no_fusion else 0
-    n_local_surfaces = batch.n_surfaces_in_batch
-    fused = n_fused > 0 and P >= (1 if n_local_surfaces <= 8192 else 3)
-    total_nodes = n_nodes_model * (world if weak else 1)
-    value = total_nodes * K / elapsed
-    if sharded:
-        n_shared = batch.n_shared_zones
-        how = {"native": "library-owned RCCL communicator, all-gather in the batch's one stream",
-               "torch": "torch.distributed.all_gather_into_tensor", "none": "no collective issued"}[sm.collective]
-        parallelism = ("surfaces sharded %d-way %s, zones replicated; %d zones shared between ranks (%s)" % (
-            world, "by rank-local models" if weak else "along the zone-connected clusters (heat_partition)", n_shared, how))
-    else:
-        n_shared = 0
-        parallelism = "single GPU"
-    result = {
-        "metric": "surface-node-updates/sec",
-        "value": value,
-        "unit": "node-updates/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": W,
-        "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak" if weak else "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "sub_timesteps_per_sec": K / elapsed,
-        "config": {
-            "workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
-            "config": args.config,
-            "surfaces": int(md["n_surfaces"]) * (world if weak else 1), "nodes": total_nodes,
-            "zones": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
-            "surfaces_on_rank0": n_local_surfaces,
-            "kernel_classes_rank0[M4,M8,M16,small,general]": counts,
-            "surfaces_in_cluster_resident_march_rank0": n_fused,
-            "n_shared_zones": n_shared,
-            "parallelism": parallelism,
-        },
-    }
-    nodes_local = batch.n_nodes
-    if n_samples > 0 and fused:
-        # The cluster-resident march re-uses the state on chip: its HBM traffic is a small fraction of the
-        # streaming byte count, and what bounds it is VALU issue. achieved = VALU wave-instructions per second, with
-        # the instruction count per tile and sub-timestep from the committed SQ counters of this workload.
-        counters, src = committed_counters(args.config, int(md["n_surfaces"]), n_nodes_model, "fused", P)
-        rl = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-              "kernel": "k_surfaces_fast<M,...,FUSED> (cluster-resident march: %d sub-timesteps of iterate_surfaces + zone "
-                        "balance per launch, node temperatures in registers)" % P,
-              "sub_timesteps_per_launch": P, "kernel_us": surf_us * P, "kernel_us_per_sub_timestep": surf_us,
-              "substep_us": substep_us, "samples": n_samples, "counters_source": src,
-              "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction"}
-        if counters:
-            valu = counters["valu_insts_per_launch"] * (nodes_local / counters["workload"]["nodes_total"]) / counters["workload"]["substeps_per_launch"]
-            rl["achieved"] = valu / (surf_us * 1e-6) / 1e9
-            rl["frac"] = rl["achieved"] / VALU_PEAK_GINST
-            rl["valu_insts_per_sub_timestep"] = valu
-            rl["traffic"] = counters.get("hbm_traffic_bytes_per_launch")
-            if rl["traffic"]:  # (a rank of a sharded run launches its share of the counted workload)
-                rl["traffic"] *= nodes_local / counters["workload"]["nodes_total"]
-            if rl["traffic"]:
-                rl["hbm_gbs_measured_traffic"] = rl["traffic"] / (surf_us * P * 1e-6) / 1e9
-                rl["hbm_frac_measured_traffic"] = rl["hbm_gbs_measured_traffic"] / HBM_PEAK_GBS
+    result = {"metric": "surface-node-updates/sec", "value": None, "unit": "node-updates/s", "n_gpus": world,
+              "steps": K, "warmup": W, "ms_per_step": None, "higher_is_better": True,
+              "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "kernel_sources_sha256": kernel_source_hash()[:16]}
+    try:
+        if sharded:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29511")
+                # (HEAT_AMD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU, where
+                # RCCL refuses a second rank on the same device; only barriers and the timing reduction go through it)
+                backend = os.environ.get("HEAT_AMD_BENCH_BACKEND", "nccl")
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                else:
+                    dist.init_process_group(backend, rank=rank, world_size=world)
+            result.update(sharded_leg(args.config, args, K, W, P, seed, rank, world, local_rank, weak))
+            if world > 1 and not weak and not args.no_exchange_leg and args.config == "headline":
+                # the collective at work: config 3's ring of zones is one cluster, cut by surface ranges
+                try:
+                    leg = sharded_leg("3", args, args.config_steps, 20, P, seed, rank, world, local_rank, False)
+                except Exception as e:  # noqa: BLE001 — the main line still goes out
+                    leg = {"error": "%s: %s" % (type(e).__name__, e)}
+                result["exchange_leg"] = leg
+            dist.destroy_process_group()
         else:
-            rl["achieved"] = rl["frac"] = rl["traffic"] = None
-        rl["equivalent_streaming_gbs"] = algorithmic_bytes / (surf_us * 1e-6) / 1e9
-        rl["equivalent_streaming_note"] = ("algorithmic (streaming) bytes of the same sub-timesteps / kernel time: what a "
-                                           "streamed march would have to sustain; not a roofline fraction")
-        result["roofline"] = rl
-    elif n_samples > 0:
-        counters, src = committed_counters(args.config, int(md["n_surfaces"]), n_nodes_model, "streamed")
-        result["roofline"] = hbm_roofline(algorithmic_bytes, surf_us, substep_us, n_samples, counters, src,
-                                          "streamed march: k_surfaces_stream / k_surfaces_fast (iterate_surfaces: RK4 stencil "
-                                          "+ boundary updates, one sub-timestep per launch)")
-        # the same bytes over the wall-clock time of a step of the timed region (graph replay, launches and all)
-        result["roofline"]["frac_wall_clock_step"] = algorithmic_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS
-    extras = rank == 0 and world == 1 and not sharded and not args.no_extras
-    if extras:
-        # the drop-in call on a caller-owned host state (PCIe-inclusive; never `value`)
-        st = state.copy()
-        wcall = mdl.weather_series(P, dt)
-        batch.march(st, wcall)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            batch.march(st, wcall)
-        tc = (time.perf_counter() - t0) / reps
-        result["caller_owned"] = {"value": n_nodes_model * P / tc, "unit": "node-updates/s", "ms_per_call": tc * 1e3,
-                                  "sub_timesteps_per_call": P, "state_megabytes": st.nbytes / 1e6,
-                                  "note": "heat_batch_march: inputs up, march, outputs down, caller's pageable numpy array"}
-        # how the sub-timesteps per march call change the picture (the reference's config 1 runs 2 per call)
-        sens = {}
-        for p in (2, 5, 20):
-            wv = mdl.weather_series(p, dt)
-            calls = max(2, 40 // p)
-            batch.march_resident(wv)
-            batch.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                batch.march_resident(wv)
-            batch.synchronize()
-            sens[str(p)] = n_nodes_model * p * calls / (time.perf_counter() - t0)
-        result["value_by_substeps_per_march"] = sens
-    if rank == 0 and world == 1 and not sharded and fused and not args.no_streaming_leg:
-        batch.close()
-        result["roofline_streaming"] = streaming_leg(md, state, args, dt)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(md, state, dt)
-    if sharded:
-        import torch.distributed as dist
-        sm.close()
-        dist.destroy_process_group()
-    else:
-        batch.close()
+            result.update(single_gpu_leg(args.config, args, K, W, P, seed, local_rank, True, 12.0))
+            if args.config == "headline" and not args.no_configs:
+                result["configs"] = {}
+                for name in ("3", "5", "2", "partitions"):
+                    t0 = time.perf_counter()
+                    try:
+                        leg = single_gpu_leg(name, args, args.config_steps, 20, P, seed, local_rank, False, 4.0)
+                    except Exception as e:  # noqa: BLE001 — a failing leg must not take the line with it
+                        leg = {"error": "%s: %s" % (type(e).__name__, e)}
+                    leg["leg_seconds"] = time.perf_counter() - t0
+                    result["configs"][name] = leg
+    except Exception as e:  # noqa: BLE001 — the line goes out whatever happened, and says what did
+        traceback.print_exc(file=sys.stderr)
+        result["error"] = "%s: %s" % (type(e).__name__, e)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if "error" in result:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,8 @@ SYMBOLS = [
     ("heat_batch_comm_init_ex", C.c_int, [_H, C.POINTER(C.c_uint8), _i32p, C.c_int32]),
     ("heat_batch_set_owned_zones", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("heat_batch_n_shared_zones", C.c_int32, [_H]),
+    ("heat_batch_comm_ranks", C.c_int32, [_H]),
+    ("heat_batch_comm_destroy", C.c_int, [_H]),
     ("heat_batch_set_fusion", C.c_int, [_H, C.c_int32]),
     ("heat_batch_n_fused_surfaces", C.c_int64, [_H]),
     ("heat_batch_n_fused_launches", C.c_int64, [_H]),
@@ -438,6 +440,14 @@ class HeatBatch:
     @property
     def n_shared_zones(self):
         return int(self._L.heat_batch_n_shared_zones(self._h))
+
+    @property
+    def comm_ranks(self):
+        """Ranks of the batch's own RCCL communicator (0: none)."""
+        return int(self._L.heat_batch_comm_ranks(self._h))
+
+    def comm_destroy(self):
+        _check(self._L.heat_batch_comm_destroy(self._h))
 
     def set_fusion(self, enabled):
         """Cluster-resident march on/off (off: every surface is streamed one sub-timestep per launch)."""

@@ -1374,6 +1374,25 @@ int heat_batch_comm_init_ex(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES],
 
 int32_t heat_batch_n_shared_zones(const heat_batch *b) { return (b && b->shared_set) ? b->n_shared : 0; }
 
+int32_t heat_batch_comm_ranks(const heat_batch *b) { return (b && b->comm) ? b->n_ranks : 0; }
+
+int heat_batch_comm_destroy(heat_batch *b) {
+    if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
+    if (!b->comm) return HEAT_OK;
+    int rc = select_device(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    Rccl *r = rccl();
+    if (r) (void)r->CommDestroy(b->comm);
+    b->comm = nullptr;
+    // back to "sharded batch without a communicator": the caller agrees on the shared zones again by its own means
+    // (heat_batch_set_owned_zones / heat_batch_set_shared_zones) or gives the batch a new communicator
+    b->shared_set = false;
+    b->n_shared = 0;
+    b->d_gathered.release();
+    return HEAT_OK;
+}
+
 int heat_batch_step_zones(heat_batch *b, const double *gathered_dev, int32_t n_blocks) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
     if (n_blocks < 1) return fail(HEAT_E_INVALID_ARG, "n_blocks < 1");

@@ -121,6 +121,31 @@ def agree_on_shared_zones(local_mask, device, group=None):
     return agree_on_zones(local_mask, device, group)[0]
 
 
+def native_comm_or_fallback(comm_init, comm_destroy, agree_min, log=None):
+    """The collective decision around heat_batch_comm_init: ``comm_init()`` is tried on every rank (it raises on
+    failure — HEAT_E_COMM: ncclCommInitRank refused, a rank without RCCL, ...); the ranks then agree on the WORST
+    outcome (``agree_min(ok) -> min over ranks``, an all-reduce over the host's own process group). When any rank
+    failed, the ranks that did get a communicator give it up (``comm_destroy()``), so that EVERY rank takes the same
+    fallback. Returns (True, None) when all ranks hold a communicator, else (False, message of this rank's failure or
+    a note that another rank failed). Never raises for a failed comm_init: a sharded run must not lose a rank there."""
+    err = None
+    try:
+        comm_init()
+        ok = 1
+    except Exception as e:  # noqa: BLE001 — HeatError, or whatever a host's own comm_init raises
+        ok = 0
+        err = "%s: %s" % (type(e).__name__, e)
+    all_ok = int(agree_min(ok))
+    if all_ok:
+        return True, None
+    if ok:
+        comm_destroy()
+        err = "heat_batch_comm_init failed on another rank"
+    if log:
+        log("heat_amd: native RCCL communicator not available on every rank (%s); falling back" % err)
+    return False, err
+
+
 class ShardedMarch:
     """Drives one rank's HeatBatch through the sharded sub-timestep with the zone exchange.
 
@@ -155,6 +180,7 @@ class ShardedMarch:
                                rank=rank, rank_of_surface=rank_of_surface, **batch_opts)
         self.shared = None
         self.exchange = None
+        self.collective_fallback = None  # why "native" was asked for and something else runs (None: it does not apply)
         forced = None if force_shared is None or len(force_shared) == 0 else np.asarray(force_shared, dtype=np.int32)
         if rank_of_surface is not None and n_shared_in_partition == 0 and forced is None:
             # heat_batch_create_shard has seen that no zone is faced from two ranks: nothing to exchange, ever
@@ -180,10 +206,23 @@ class ShardedMarch:
                     dist.broadcast(t, src=0)
                     uid = t.cpu()
                 # the zones the ranks share are agreed inside (plus the forced ones: the union, on every rank)
-                self.batch.comm_init(uid.numpy().tobytes(), extra_shared=forced)
-                return
-            print("heat_amd: RCCL cannot be loaded on every rank; using torch.distributed for the zone exchange",
-                  file=sys.stderr)
+                def agree_min(v):
+                    if not multi:
+                        return v
+                    t = torch.tensor([v], dtype=torch.int32, device=dev if on_dev else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    return int(t.item())
+
+                done, why = native_comm_or_fallback(
+                    lambda: self.batch.comm_init(uid.numpy().tobytes(), extra_shared=forced),
+                    self.batch.comm_destroy, agree_min, log=lambda m: print(m, file=sys.stderr))
+                if done:
+                    return
+                self.collective_fallback = why
+            else:
+                self.collective_fallback = "RCCL cannot be loaded on every rank"
+                print("heat_amd: RCCL cannot be loaded on every rank; using torch.distributed for the zone exchange",
+                      file=sys.stderr)
             self.collective = "torch"
         self.shared, owned = agree_on_zones(self.batch.touched_zones(), dev)
         if forced is not None:
@@ -197,6 +236,11 @@ class ShardedMarch:
     @property
     def n_shared_zones(self):
         return self.batch.n_shared_zones
+
+    @property
+    def comm_ranks(self):
+        """Ranks of the library-owned RCCL communicator (0: none — no zone shared, or the torch collective)."""
+        return self.batch.comm_ranks
 
     def march_resident(self, weather, zone_a0=None, zone_b0=None):
         """≙ ThermalModel::march on the device-resident state of this shard (asynchronous)."""

@@ -253,6 +253,14 @@ int heat_batch_comm_init_ex(heat_batch *b, const uint8_t id[HEAT_COMM_ID_BYTES],
                             int32_t n_extra);
 int heat_batch_set_owned_zones(heat_batch *b, const uint8_t *owned);
 int32_t heat_batch_n_shared_zones(const heat_batch *b);
+/* Ranks of the batch's communicator (0: it has none — single GPU, a partition that shares no zone, or a host that
+ * brings its own collective). */
+int32_t heat_batch_comm_ranks(const heat_batch *b);
+/* Gives the communicator up (ncclCommDestroy) and returns the batch to "sharded, no communicator, shared zones not
+ * agreed": for a host whose ranks found out — collectively, by their own means — that heat_batch_comm_init failed
+ * on SOME rank, and that now fall back to the split-phase calls with their own collective on EVERY rank. No-op
+ * without a communicator. (A failed heat_batch_comm_init[_ex] has already done this on the rank it failed on.) */
+int heat_batch_comm_destroy(heat_batch *b);
 
 /*
  * Cluster-resident march (on by default). ThermalModel::march runs its dt_subdivisions sub-timesteps back to back

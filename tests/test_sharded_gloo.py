@@ -238,6 +238,73 @@ def test_three_ranks_with_the_cluster_partition(case):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+def _fallback_worker(rank, world, port, q, failing_rank):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from heat_amd.sharded import ZoneExchange, native_comm_or_fallback
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = {"init": 0, "destroy": 0}
+
+        def comm_init():           # heat_batch_comm_init as it behaved on the one-GPU rehearsal: HEAT_E_COMM on a rank
+            calls["init"] += 1
+            if rank == failing_rank:
+                raise RuntimeError("[-7] ncclCommInitRank failed: invalid usage")
+
+        def comm_destroy():
+            calls["destroy"] += 1
+
+        def agree_min(v):
+            t = torch.tensor([v], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+
+        logged = []
+        done, why = native_comm_or_fallback(comm_init, comm_destroy, agree_min, log=logged.append)
+        assert calls["init"] == 1
+        if failing_rank is None:
+            assert done and why is None and calls["destroy"] == 0 and not logged
+        else:
+            # EVERY rank falls back, the ones that held a communicator have given it up, nobody raised
+            assert not done and why and len(logged) == 1
+            assert calls["destroy"] == (0 if rank == failing_rank else 1)
+            assert ("invalid usage" in why) == (rank == failing_rank)
+        # the collective the fallback uses works on every rank afterwards (nobody is stuck in, or missing from, a group)
+        ex = ZoneExchange(3, torch.device("cpu"))
+        ex.partial[:] = float(rank + 1)
+        g = ex.all_gather().numpy().reshape(world, -1)
+        assert [float(x) for x in g[:, 0]] == [float(r + 1) for r in range(world)]
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [1, 0, None])
+def test_comm_init_failure_on_one_rank_sends_every_rank_to_the_fallback(failing_rank):
+    """ShardedMarch's decision around heat_batch_comm_init (heat_amd/sharded.py, native_comm_or_fallback): a
+    HEAT_E_COMM on ANY rank must neither escape (round 2: the 4-rank rehearsal ended without its JSON line) nor leave
+    the ranks on different collectives."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, failing_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
 def test_zone_roles():
     from heat_amd.sharded import zone_roles
     cnt = np.array([2, 1, 0, 0, 3, 1, 0])

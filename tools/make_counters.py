@@ -1,7 +1,7 @@
 """profiles/<tag>_counters.json from the passes of tools/pmc_passes.sh — the file bench.py reads for `roofline`:
     python tools/make_counters.py TAG OUT_DIR KERNEL_SUBSTRING CONFIG SURFACES NODES_TOTAL MODE SUBSTEPS_PER_LAUNCH
 MODE: streamed (one sub-timestep per launch) or fused (cluster-resident march)."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 tag, d, kname, config, S, N, mode, sub = sys.argv[1:9]
 S, N, sub = int(S), int(N), int(sub)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +14,20 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         c[0] += float(r["Counter_Value"]); c[1] += 1
         c[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 m = {c: v[0] / v[1] for c, v in acc.items()}
-j = {"workload": {"config": config, "surfaces": S, "nodes_total": N, "mode": mode, "substeps_per_launch": sub},
+# the kernel sources these counters were measured on: bench.py prints "counters_stale": true (and drops every figure
+# derived from this file) when its own hash of the same files differs
+sys.path.insert(0, ROOT)
+import bench
+j = {"kernel_sources_sha256": bench.kernel_source_hash(), "kernel_sources": list(bench.KERNEL_SOURCES),
+     "workload": {"config": config, "surfaces": S, "nodes_total": N, "mode": mode, "substeps_per_launch": sub},
      "kernel": kname, "dispatches_sampled": {c: v[1] for c, v in acc.items()},
      "mean_duration_us_under_pmc": {c: v[2] / v[1] for c, v in acc.items()},
      "counters_per_launch": m}
+f64 = [m.get("SQ_INSTS_VALU_%s_F64" % k) for k in ("ADD", "MUL", "FMA", "TRANS")]
+if all(v is not None for v in f64):
+    # wave-instructions by class: adds and multiplies 1 flop per lane, FMAs 2; 64 lanes
+    j["f64_insts_per_launch"] = sum(f64)
+    j["f64_flops_per_launch"] = (f64[0] + f64[1] + 2 * f64[2]) * 64
 if "SQ_INSTS_VALU" in m:
     j["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
     j["waves_per_launch"] = m.get("SQ_WAVES")

@@ -19,7 +19,7 @@ stats() {  # name, bench args...
     echo "stats $name done"
 }
 if [ "$part" != counters ]; then
-stats headline --steps 200 --warmup 20
+stats headline --steps 200 --warmup 20 --no-configs
 stats cfg3 --config 3 --steps 100 --warmup 20
 stats cfg5 --config 5 --steps 100 --warmup 20
 stats cfg2 --config 2 --steps 200 --warmup 20
@@ -33,6 +33,8 @@ $R/tools/pmc_passes.sh $out/pmc_headline_streamed -- python3 $R/tools/run_config
 python3 $R/tools/make_counters.py ${tag}_headline_streamed $out/pmc_headline_streamed "k_surfaces_fast<16, 0, 1, 0, 0" headline 1000000 32000000 streamed 1
 $R/tools/pmc_passes.sh $out/pmc_cfg3 -- python3 $R/tools/run_config.py 3 10 1 stream
 python3 $R/tools/make_counters.py ${tag}_cfg3_streamed $out/pmc_cfg3 "k_surfaces_stream" 3 1000000 32609258 streamed 1
+$R/tools/pmc_passes.sh $out/pmc_cfg5 -- python3 $R/tools/run_config.py 5 10 1 stream
+python3 $R/tools/make_counters.py ${tag}_cfg5_streamed $out/pmc_cfg5 "k_surfaces_" 5 200000 2096503 streamed 1
 $R/tools/pmc_passes.sh $out/pmc_partitions -- python3 $R/tools/run_config.py partitions 20 2 plan
 python3 $R/tools/make_counters.py ${tag}_partitions_fused $out/pmc_partitions "k_surfaces_fast<16, 0, 1, 0, 4" partitions 999936 31997952 fused 20
 $R/tools/pmc_passes.sh $out/pmc_cfg2 -- python3 $R/tools/run_config.py 2 20 5 plan
