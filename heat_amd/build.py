@@ -56,6 +56,19 @@ def build_stamps(force=False):
     return STAMPS_LIB
 
 
+def build_variant(tag, defines, force=False):
+    """An A/B build of the product library with extra -D switches: heat_amd/lib/libheat_amd_<tag>.so, loaded through
+    HEAT_AMD_LIB by the measurement tools only (experiments; never the product)."""
+    out = os.path.join(LIB_DIR, "libheat_amd_%s.so" % tag)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(map(os.path.getmtime, deps)):
+        return out
+    os.makedirs(LIB_DIR, exist_ok=True)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] +
+                          ["-D" + d for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES])
+    return out
+
+
 EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "march_walls.cpp")
 EXAMPLE_BIN = os.path.join(LIB_DIR, "march_walls")
 
