@@ -194,6 +194,10 @@ struct heat_batch {
     // one tile list. [0]: the streamed tiles only (beside a cluster-resident march), [1]: every tile.
     DevBuf<FastTile> d_ulist[2];
     int n_ulist[2] = {0, 0};
+    // ... in three parts, one per variant of the kernel (kernels.hip: 16 nodes per lane | 8 / 4 nodes per lane and small
+    // surfaces | tiles with no-mass chunks other than facings), launched back to back: [part] = first tile, tiles
+    int ulist_part[2][kStreamVariants][2] = {};
+    bool class_has_chunks[kNumFast] = {};  // the class holds tiles with such chunks: its own launch takes the NM = 2 variant
     bool in_ulist[2][kNumFast] = {};
     bool small_in_ulist[2] = {false, false};
     DevBuf<unsigned long long> d_ucount;  // no-mass pass counters of the unified lists: [list][tile]
@@ -548,8 +552,13 @@ int rebuild_unified(heat_batch *b) {
         HIP_TRY(b->d_ucount.zeros(2 * b->ucount_stride));
     }
     const int ns = b->n_small_plain_tiles;
+    for (int c = 0; c < kNumFast; c++) {
+        b->class_has_chunks[c] = false;
+        for (const FastTile &ft : b->h_tiles_cur[c]) b->class_has_chunks[c] = b->class_has_chunks[c] || (ft.k & kTileChunkyBit) != 0;
+    }
     for (int v = 0; v < 2; v++) {
-        std::vector<FastTile> fast;
+        // the three parts (kernels.hip, k_surfaces_stream): wide | light | chunks
+        std::vector<FastTile> part[kStreamVariants];
         int n_classes = 0;
         for (int mi = 2; mi >= 0; mi--)  // 16 nodes per lane first: the heaviest tiles lead
             for (int c = mi * 6; c < mi * 6 + 6; c++) {
@@ -558,8 +567,9 @@ int rebuild_unified(heat_batch *b) {
                 n_classes += n > 0;
                 for (int t = 0; t < n; t++) {
                     FastTile ft = b->h_tiles_cur[c][t];
+                    const bool chunks = (ft.k & kTileChunkyBit) != 0;
                     ft.k = (int16_t)((ft.k & (0x1ff | kTileMixedBit | kTileChunkyBit)) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
-                    fast.push_back(ft);
+                    part[mi == 2 ? 0 : (chunks ? 2 : 1)].push_back(ft);
                 }
             }
         // worth it when it replaces two launches or more (a class on its own keeps its own persistent kernel)
@@ -567,30 +577,41 @@ int rebuild_unified(heat_batch *b) {
         b->n_ulist[v] = 0;
         for (int c = 0; c < kNumFast; c++) b->in_ulist[v][c] = use && eligible(c);
         b->small_in_ulist[v] = use && ns > 0;
+        for (int q = 0; q < kStreamVariants; q++) b->ulist_part[v][q][0] = b->ulist_part[v][q][1] = 0;
         if (!use) continue;
-        // the latency-bound small tiles are spread evenly through the list
-        const size_t N = fast.size() + (size_t)ns;
-        std::vector<FastTile> list(N);
-        std::vector<uint8_t> taken(N, 0);
-        for (int j = 0; j < ns; j++) {
-            size_t pos = (size_t)(((double)j + 0.5) * (double)N / (double)ns);
-            if (pos >= N) pos = N - 1;
-            while (taken[pos]) pos = (pos + 1) % N;
-            const GeneralTile &g = b->h_gen_tiles_cur[j];
-            FastTile ft;
-            ft.node_base = g.node_base;
-            ft.surf_base = g.surf_base;
-            ft.k = (int16_t)(kStreamKindSmall << kStreamKindShift);
-            ft.G = (int16_t)g.G;
-            list[pos] = ft;
-            taken[pos] = 1;
+        // the latency-bound small tiles are spread evenly through the light part
+        {
+            const std::vector<FastTile> fast = part[1];
+            const size_t N = fast.size() + (size_t)ns;
+            std::vector<FastTile> list(N);
+            std::vector<uint8_t> taken(N, 0);
+            for (int j = 0; j < ns; j++) {
+                size_t pos = (size_t)(((double)j + 0.5) * (double)N / (double)ns);
+                if (pos >= N) pos = N - 1;
+                while (taken[pos]) pos = (pos + 1) % N;
+                const GeneralTile &g = b->h_gen_tiles_cur[j];
+                FastTile ft;
+                ft.node_base = g.node_base;
+                ft.surf_base = g.surf_base;
+                ft.k = (int16_t)(kStreamKindSmall << kStreamKindShift);
+                ft.G = (int16_t)g.G;
+                list[pos] = ft;
+                taken[pos] = 1;
+            }
+            size_t q = 0;
+            for (size_t pos = 0; pos < N; pos++)
+                if (!taken[pos]) list[pos] = fast[q++];
+            part[1] = list;
         }
-        size_t q = 0;
-        for (size_t pos = 0; pos < N; pos++)
-            if (!taken[pos]) list[pos] = fast[q++];
-        if (N > b->ucount_stride) return fail(HEAT_E_SIZE, "unified tile list grew beyond its counters");
-        b->n_ulist[v] = (int)N;
-        HIP_TRY(b->d_ulist[v].upload(list));
+        std::vector<FastTile> all;
+        for (int q = 0; q < kStreamVariants; q++) {
+            b->ulist_part[v][q][0] = (int)all.size();
+            b->ulist_part[v][q][1] = (int)part[q].size();
+            all.insert(all.end(), part[q].begin(), part[q].end());
+        }
+        if (all.size() > b->ucount_stride) return fail(HEAT_E_SIZE, "unified tile list grew beyond its counters");
+        b->n_ulist[v] = (int)all.size();
+        HIP_TRY(b->d_ulist[v].upload(all));
     }
     return HEAT_OK;
 }
@@ -634,9 +655,21 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         (void)hipEventRecord(b->ev_fork, b->stream);
         for (int i = 0; i < heat_batch::kSideStreams; i++) (void)hipStreamWaitEvent(b->side[i], b->ev_fork, 0);
     }
-    if (unified)
-        launch_surfaces_stream(b->d_ulist[ul].p, b->n_ulist[ul], b->na, b->gen_base, b->sa, b->d_weather.p, b->d_step.p,
-                               step_fixed, b->d_zone_T.p, b->d_flags.p, b->d_ucount.p + ul * b->ucount_stride, b->n_cu, next_stream());
+    if (unified) {
+        // the parts follow each other on ONE stream (a dependency between two streams costs more than the tail of a part)
+        hipStream_t us = next_stream();
+        // the light part first: its wavefronts are the latency-bound ones, the wide part's tail is the shorter
+        static const int order_env = getenv("HEAT_AMD_STREAM_ORDER") ? atoi(getenv("HEAT_AMD_STREAM_ORDER")) : 0;  // measurement
+        const int seq[2][kStreamVariants] = {{1, 2, 0}, {0, 1, 2}};
+        for (int qi = 0; qi < kStreamVariants; qi++) {
+            const int q = seq[order_env ? 1 : 0][qi];
+            const int first = b->ulist_part[ul][q][0], n = b->ulist_part[ul][q][1];
+            if (n > 0)
+                launch_surfaces_stream(q, b->d_ulist[ul].p + first, n, b->na, b->gen_base, b->sa, b->d_weather.p, b->d_step.p,
+                                       step_fixed, b->d_zone_T.p, b->d_flags.p,
+                                       b->d_ucount.p + ul * b->ucount_stride + first, b->n_cu, us);
+        }
+    }
     // work of each class in node slots, to size the persistent grids
     double work[kNumFast], total_work = 0.0;
     for (int c = 0; c < kNumFast; c++) {
@@ -651,7 +684,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     for (int q = 0; q < kNumFast; q++) {
         const int c = order[q];
         if (nt[c] <= 0) continue;
-        launch_surfaces_fast(kFastM[c], kFastNM[c], kFastPAL[c], kFastCAV[c], work[c] / total_work,
+        launch_surfaces_fast(kFastM[c], kFastNM[c] ? (b->class_has_chunks[c] ? 2 : 1) : 0, kFastPAL[c], kFastCAV[c], work[c] / total_work,
                              b->d_fast_tiles[c].p, nt[c], b->na,
                              b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
                              b->d_nomass_iters.p + b->nm_count_base[c], b->n_cu, next_stream());

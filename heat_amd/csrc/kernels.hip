@@ -136,48 +136,44 @@ __device__ __forceinline__ double from_next_lane(double v) { return dpp_rotate_f
 // Four applications of A as before, but no per-stage accumulator: 20 f64 operations per node and sub-timestep instead
 // of 24, the same values up to rounding (1e-15 relative against the oracle's literal stages; tested at 1e-9).
 // Every application consumes its input in place: x_j is dead once f_j is formed.
-//   AFFINE: the application includes q (the face sources qF, qB) — the first one only.
-//   FULL: every surface of the tile fills its last lane (n == k M), so the last node is j == M-1.
+//
+// The faces cost no select inside the stages: the caller hands in EFFECTIVE conductances —
+//   Ue[last node] = hB (the reference's UValue::Back there is 0) with the node "behind" it held at 0: padding slots
+//                   are 0 in T, v and z (V = 0 keeps them there), and a surface's last lane takes 0 for its right neighbour;
+//   ULe = hF for a surface's first lane, which takes 0 for its left neighbour —
+// so that f_last = hB (0 - x_last) and f_{-1} = hF (x_0 - 0) fall out of the plain stencil, wherever the last node
+// sits inside its lane. The sources qF, qB enter the first application only (AFFINE), qB through qsel(j).
+// No value of a neighbouring surface (possibly NaN) ever enters: the zeros above replace exactly those.
 //   put(j, y): receives (A x [+ q])_j.
-template <int M, bool FULL, bool AFFINE, typename VF, typename PUT>
-__device__ __forceinline__ void apply_A(const double (&x)[M], VF V, const double (&U)[M], double UL, bool is_first,
-                                        bool is_last, int jl, double hF, double qF, double hB, double qB, PUT put) {
-    double xl = from_prev_lane(x[M - 1]);
-    const double xr = from_next_lane(x[0]);
-    // never let another surface's value (possibly NaN) in: the first lane has no left neighbour
-    double fprev = is_first ? (AFFINE ? (hF * x[0] - qF) : (hF * x[0])) : UL * (x[0] - xl);
+template <int M, bool AFFINE, typename VF, typename QF, typename PUT>
+__device__ __forceinline__ void apply_A(const double (&x)[M], VF V, const double (&Ue)[M], double ULe, bool is_first,
+                                        bool is_last, double qF, QF qsel, PUT put) {
+    const double xl_raw = from_prev_lane(x[M - 1]);
+    const double xr_raw = from_next_lane(x[0]);
+    const double xl = is_first ? 0.0 : xl_raw;
+    const double xr = is_last ? 0.0 : xr_raw;
+    double fprev = ULe * (x[0] - xl);
+    if (AFFINE) fprev -= qF;
 #pragma unroll
     for (int j = 0; j < M; j++) {
         const double xj = x[j];
-        double f;
-        if (j == M - 1) {
-            f = is_last ? 0.0 : U[j] * (xr - xj);  // the last lane's right neighbour belongs to another surface
-        } else {
-            f = U[j] * (x[j + 1] - xj);
-        }
-        const double fb = AFFINE ? (qB - hB * xj) : (0.0 - hB * xj);
-        if (FULL) {
-            if (j == M - 1) f = is_last ? fb : f;
-        } else {
-            f = (is_last && j == jl) ? fb : f;
-        }
+        double f = Ue[j] * (((j == M - 1) ? xr : x[j + 1]) - xj);
+        if (AFFINE) f += qsel(j);
         put(j, V(j) * (f - fprev));
         fprev = f;
     }
 }
 
-template <int M, bool FULL, typename VF>
-__device__ __forceinline__ void rk4_horner(double (&T)[M], VF V, const double (&U)[M], double UL, bool is_first,
-                                           bool is_last, int jl, double hF, double qF, double hB, double qB) {
+// qF: 0 unless this lane is its surface's first; qsel(j): qB at the surface's last node, else 0.
+template <int M, typename VF, typename QF>
+__device__ __forceinline__ void rk4_horner(double (&T)[M], VF V, const double (&Ue)[M], double ULe, bool is_first,
+                                           bool is_last, double qF, QF qsel) {
     double v[M], z[M];
-    apply_A<M, FULL, true>(T, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB,
-                           [&](int j, double y) { v[j] = y * (1.0 / 24.0); });
-    apply_A<M, FULL, false>(v, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB,
-                            [&](int j, double y) { z[j] = 4.0 * v[j] + y; });
-    apply_A<M, FULL, false>(z, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB,
-                            [&](int j, double y) { z[j] = 12.0 * v[j] + y; });
-    apply_A<M, FULL, false>(z, V, U, UL, is_first, is_last, jl, hF, qF, hB, qB,
-                            [&](int j, double y) { T[j] = (T[j] + 24.0 * v[j]) + y; });
+    apply_A<M, true>(T, V, Ue, ULe, is_first, is_last, qF, qsel, [&](int j, double y) { v[j] = y * (1.0 / 24.0); });
+    apply_A<M, false>(v, V, Ue, ULe, is_first, is_last, qF, qsel, [&](int j, double y) { z[j] = 4.0 * v[j] + y; });
+    apply_A<M, false>(z, V, Ue, ULe, is_first, is_last, qF, qsel, [&](int j, double y) { z[j] = 12.0 * v[j] + y; });
+    apply_A<M, false>(z, V, Ue, ULe, is_first, is_last, qF, qsel,
+                      [&](int j, double y) { T[j] = (T[j] + 24.0 * v[j]) + y; });
 }
 
 // ---------------------------------------------------------------------------
@@ -586,7 +582,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     // (wave-uniform) the tile holds no-mass chunks other than one-node facings: chunks inside the wall, of two nodes
     // (streamed variants only: the cluster-resident march leaves clusters with such walls to the streamed kernels — the
     // chunk loop's registers would cost every fused NM variant, used or not)
-    const bool chunky = NM && PAL && !FUSED && (tile.k & kTileChunkyBit) != 0;
+    // NM = 2 compiles that chunk loop in; NM = 1 knows one-node facings only (its face terms live in ten registers
+    // fewer: what puts the 8-node streamed body under the 168 registers of three wavefronts per SIMD)
+    constexpr bool kChunks = NM == 2 && PAL && !FUSED;
+    const bool chunky = kChunks && (tile.k & kTileChunkyBit) != 0;
     const int k = tile.k & 0xff;                              // lanes per surface; mixed: lanes of the tile
     const bool full = (tile.k & 0x100) != 0;
     const int G = tile.G;
@@ -824,6 +823,8 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     // (NM: the terms of a face are kept for the no-mass chunk that may sit at it, below)
     double fF_hs = 0.0, fF_rhs = 0.0, fF_rad = 0.0, fF_air = 0.0, fF_sol = 0.0;  // front face of this lane's surface
     double fB_hs = 0.0, fB_rhs = 0.0, fB_rad = 0.0, fB_air = 0.0, fB_sol = 0.0;  // back face
+    (void)fF_hs; (void)fF_rhs; (void)fF_rad; (void)fF_air; (void)fF_sol;
+    (void)fB_hs; (void)fB_rhs; (void)fB_rad; (void)fB_air; (void)fB_sol;
     auto add_face = [&](const SideConst &cc, const SideDyn &dd, bool back, double air_t, double rad_t, double forced,
                         int rec, bool use_front_T, double &h_out, double &q_out) {
         h_out = 0.0;
@@ -833,7 +834,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         const double rhs = rad_hs(cc.emis, rad_t, surf_t);  // surface.rs:941-948
         const double sol = dd.solar;                        // absorbed: alpha * irradiance, formed at upload
         if constexpr (NM) {
-            if constexpr (PAL && !FUSED) {
+            if constexpr (kChunks) {
                 fF_hs = back ? fF_hs : hs; fF_rhs = back ? fF_rhs : rhs; fF_rad = back ? fF_rad : rad_t;
                 fF_air = back ? fF_air : air_t; fF_sol = back ? fF_sol : sol;
                 fB_hs = back ? hs : fB_hs; fB_rhs = back ? rhs : fB_rhs; fB_rad = back ? rad_t : fB_rad;
@@ -918,7 +919,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         }
     }
 
-    if constexpr (NM && PAL && !FUSED) {
+    if constexpr (kChunks) {
         // ---- no-mass chunks (march_nomass, surface.rs:790-898), before the massive nodes march (surface.rs:950-965) ----
         // A chunk is one or two consecutive no-mass nodes between massive nodes and / or a face: a thin facing, two
         // light layers at a face (render on insulation), an insulation layer and an air gap inside a cavity wall. Its
@@ -1030,8 +1031,32 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     }
 
     // ---- RK4 (surface.rs:228-308) ----
-    if (full) rk4_horner<M, true>(T, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB);
-    else rk4_horner<M, false>(T, Vat, U, UL, is_first, is_last, jl, hF, qF, hB, qB);
+    {
+        // effective conductances of the two faces (apply_A): once per sub-timestep, not per stage and node
+        const double hBe = is_last ? hB : 0.0;
+        if (full) {
+            U[M - 1] = is_last ? hB : U[M - 1];
+        } else {
+#pragma unroll
+            for (int j = 0; j < M; j++) U[j] = (j == jl) ? U[j] + hBe : U[j];  // (the last node's own U is 0: UValue::Back)
+        }
+        const double ULe = is_first ? hF : UL;
+        const double qFe = is_first ? qF : 0.0;
+        const double qBe = is_last ? qB : 0.0;
+        if (full) {
+            rk4_horner<M>(T, Vat, U, ULe, is_first, is_last, qFe, [&](int j) -> double { return (j == M - 1) ? qBe : 0.0; });
+        } else {
+            rk4_horner<M>(T, Vat, U, ULe, is_first, is_last, qFe, [&](int j) -> double { return (j == jl) ? qBe : 0.0; });
+        }
+        if constexpr (FUSED) {  // U lives on: back to UValue::Back at the last node
+            if (full) {
+                U[M - 1] = is_last ? 0.0 : U[M - 1];
+            } else {
+#pragma unroll
+                for (int j = 0; j < M; j++) U[j] = (is_last && j == jl) ? 0.0 : U[j];
+            }
+        }
+    }
 
     // ---- write back node temperatures (model.rs:145-147); FUSED: after the last sub-timestep only ----
     if constexpr (!FUSED) {
@@ -1234,7 +1259,18 @@ next_block:
 // hold (per-node constants, gas cavities, the catch-all) keep their own launches.
 constexpr int kTileKindShift = 9;
 constexpr int kTileNmBit = 1 << 11;
-__global__ void __launch_bounds__(256, 2)
+// The kernel comes in three variants, each under the launch bounds its bodies can keep, because a wavefront of this
+// latency-bound walk is parked at s_waitcnt for most of its life (SQ_WAIT_ANY 59-63 % at two wavefronts per SIMD):
+//   kStreamWide   tiles of 16 nodes per lane (no facings): 2 wavefronts per SIMD (T, v, z, U, V alone are 160 registers)
+//   kStreamLight  tiles of 8 / 4 nodes per lane with one-node facings at most, and the small surfaces: 3 wavefronts
+//                 per SIMD (<= 168 registers)
+//   kStreamChunks tiles of 8 / 4 nodes per lane that hold other no-mass chunks (inside the wall, of two nodes): the
+//                 chunk loop's registers, 2 wavefronts per SIMD
+// The host sorts a batch's tiles into one list per variant (batch.hip, rebuild_unified) and launches them back to
+// back on the batch's stream.
+enum { kStreamWide = 0, kStreamLight = 1, kStreamChunks = 2 };
+template <int VARIANT>
+__global__ void __launch_bounds__(256, VARIANT == kStreamLight ? 3 : 2)
 k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base, SideArrays sd,
                   const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                   const double *__restrict__ zone_T, int *__restrict__ flags,
@@ -1251,6 +1287,7 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
     const FusedBlock blk{0, 0, 0, 0, 0, 0};
     const FusedArgs fa{};
     if (wave0 >= n_tiles) return;
+    constexpr int kNm = VARIANT == kStreamChunks ? 2 : 1;
     // (the tile descriptor is wave-uniform: scalar loads)
     for (int wv = wave0; wv < n_tiles; wv += n_waves) {
         const int w = __builtin_amdgcn_readfirstlane(wv);
@@ -1258,27 +1295,28 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
         const int kind = (tile.k >> kTileKindShift) & 3;
         const bool nm = (tile.k & kTileNmBit) != 0;
         tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit | kTileChunkyBit));
-        switch (kind) {
-        case 2:
+        if constexpr (VARIANT == kStreamWide) {
             fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
                                             zone_T, flags, nomass_iters, fa, write_out);
-            break;
-        case 1:
-            fast_tile_march<8, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
-                                           flags, nomass_iters, fa, write_out);
-            break;
-        case 0:
-            fast_tile_march<4, 1, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather, zone_T,
-                                           flags, nomass_iters, fa, write_out);
-            break;
-        default: {
-            unsigned int tot = small_tile_march<0>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, weather[step0],
-                                                   zone_T, flags);
+        } else {
+            switch (kind) {
+            case 1:
+                fast_tile_march<8, kNm, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
+                                                 zone_T, flags, nomass_iters, fa, write_out);
+                break;
+            case 0:
+                fast_tile_march<4, kNm, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
+                                                 zone_T, flags, nomass_iters, fa, write_out);
+                break;
+            default: {
+                unsigned int tot = small_tile_march<0>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, weather[step0],
+                                                       zone_T, flags);
 #pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
-            if (lane == 0 && tot) nomass_iters[w] += tot;
-            break;
-        }
+                for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
+                if (lane == 0 && tot) nomass_iters[w] += tot;
+                break;
+            }
+            }
         }
     }
 }
@@ -1841,23 +1879,29 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     case 1: HEAT_LAUNCH_FAST(MM, 0, 1, 0); break;             \
     case 2: HEAT_LAUNCH_FAST(MM, 0, 1, 1); break;             \
     case 3: HEAT_LAUNCH_FAST(MM, 1, 0, 0); break;             \
-    case 4: HEAT_LAUNCH_FAST(MM, 1, 1, 0); break;             \
-    default: HEAT_LAUNCH_FAST(MM, 1, 1, 1); break;            \
+    case 4: if (nm == 2) HEAT_LAUNCH_FAST(MM, 2, 1, 0); else HEAT_LAUNCH_FAST(MM, 1, 1, 0); break; \
+    default: if (nm == 2) HEAT_LAUNCH_FAST(MM, 2, 1, 1); else HEAT_LAUNCH_FAST(MM, 1, 1, 1); break; \
     }
     if (M == 4) { HEAT_LAUNCH_M(4) } else if (M == 8) { HEAT_LAUNCH_M(8) } else { HEAT_LAUNCH_M(16) }
 #undef HEAT_LAUNCH_M
 #undef HEAT_LAUNCH_FAST
 }
 
-// grid: persistent, two 4-wave blocks per compute unit (256 registers per lane), capped by the tile count.
-void launch_surfaces_stream(const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
+// grid: persistent — as many 4-wave blocks per compute unit as the variant's launch bounds admit — capped by the tile count.
+void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
                             int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st) {
     if (n_tiles <= 0) return;
-    static const int per_cu = getenv("HEAT_AMD_STREAM_BLOCKS") ? atoi(getenv("HEAT_AMD_STREAM_BLOCKS")) : 2;
-    const int grid = std::min(blocks_for_waves(n_tiles), n_cu * std::max(per_cu, 1));
-    hipLaunchKernelGGL(k_surfaces_stream, dim3(grid), dim3(256), pal_lds_bytes(na), st, tiles, n_tiles, na, gen_base, sa, weather, step_ptr,
-                       step_fixed, zone_T, flags, nomass_iters);
+    static const int per_cu_env = getenv("HEAT_AMD_STREAM_BLOCKS") ? atoi(getenv("HEAT_AMD_STREAM_BLOCKS")) : 0;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (variant == kStreamLight ? 3 : 2);
+    const int grid = std::min(blocks_for_waves(n_tiles), n_cu * per_cu);
+#define HEAT_LAUNCH_STREAM(V)                                                                                       \
+    hipLaunchKernelGGL(k_surfaces_stream<V>, dim3(grid), dim3(256), pal_lds_bytes(na), st, tiles, n_tiles, na, gen_base, sa, weather, \
+                       step_ptr, step_fixed, zone_T, flags, nomass_iters)
+    if (variant == kStreamWide) HEAT_LAUNCH_STREAM(kStreamWide);
+    else if (variant == kStreamLight) HEAT_LAUNCH_STREAM(kStreamLight);
+    else HEAT_LAUNCH_STREAM(kStreamChunks);
+#undef HEAT_LAUNCH_STREAM
 }
 
 // Cluster-resident march of one class: one workgroup of `max_waves` (4 or 8) wavefronts per FusedBlock, fa.n_sub

@@ -10,6 +10,7 @@ struct SlotArrays {
     const int64_t *hs_f, *hs_b, *flow_f, *flow_b, *solar_f, *solar_b, *ir_f, *ir_b;
 };
 
+// nm: 0 all-massive, 1 one-node no-mass facings, 2 any no-mass chunk of one or two nodes (palette classes)
 void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
                           const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
@@ -18,7 +19,10 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
 constexpr int kStreamKindShift = 9;
 constexpr int kStreamKindSmall = 3;
 constexpr int kStreamNmBit = 1 << 11;
-void launch_surfaces_stream(const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
+// variant: 0 tiles of 16 nodes per lane, 1 tiles of 8 / 4 nodes per lane with one-node facings at most + small surfaces,
+// 2 tiles of 8 / 4 nodes per lane with other no-mass chunks (kernels.hip, k_surfaces_stream)
+constexpr int kStreamVariants = 3;
+void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
                             int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st);
 int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves, int pal_stride);
