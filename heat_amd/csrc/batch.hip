@@ -437,7 +437,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
         b->zone_rows = rows_env ? atoi(rows_env) : ((int64_t)p.zone_entries.size() <= 24 * (int64_t)b->n_zones);
     }
     HIP_TRY(b->d_zone_contrib.zeros(p.zone_entries.size()));
-    HIP_TRY(b->d_zone_T.zeros(Z));
+    HIP_TRY(b->d_zone_T.zeros(std::max<int64_t>(Z, 1)));  // (never empty: the surface kernels gather unconditionally)
     HIP_TRY(b->d_zone_a0.zeros(Z));
     HIP_TRY(b->d_zone_b0.zeros(Z));
     HIP_TRY(b->d_partial.zeros(2 * Z));

@@ -299,15 +299,28 @@ __device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, co
     const double *Tg = na.T + tile.node_base + lane;
     const double *Ug = na.U + tile.node_base + lane;
     const int64_t gofs = tile.node_base - gen_base + lane;
+    // (every load goes out at once, from the slot of a node the surface has — j clamped —, and is masked afterwards:
+    // loads under `j < nn` branches wait for each other, one memory round trip per node)
+    double tl[kSmallNodes], ul[kSmallNodes], af[kSmallNodes], ab[kSmallNodes];
+    int cl[kSmallNodes];
+#pragma unroll
+    for (int j = 0; j < kSmallNodes; j++) {
+        const int64_t jc = (int64_t)min(j, nn - 1) * kWave;
+        tl[j] = Tg[jc];
+        ul[j] = Ug[jc];
+        af[j] = na.alpha_f[gofs + jc];
+        ab[j] = na.alpha_b[gofs + jc];
+        cl[j] = CAV ? na.cav[gofs + jc] : -1;
+    }
 #pragma unroll
     for (int j = 0; j < kSmallNodes; j++) {
         const bool v = j < nn;
-        T[j] = v ? Tg[(int64_t)j * kWave] : 0.0;
-        Us[j] = v ? Ug[(int64_t)j * kWave] : 0.0;
-        cav[j] = (CAV && v) ? na.cav[gofs + (int64_t)j * kWave] : -1;
+        T[j] = v ? tl[j] : 0.0;
+        Us[j] = v ? ul[j] : 0.0;
+        cav[j] = (CAV && v) ? cl[j] : -1;
         // surface.rs:930-931
-        double sj = v ? na.alpha_f[gofs + (int64_t)j * kWave] * df.solar : 0.0;
-        sj += v ? na.alpha_b[gofs + (int64_t)j * kWave] * db.solar : 0.0;
+        double sj = v ? af[j] * df.solar : 0.0;
+        sj += v ? ab[j] * db.solar : 0.0;
         sol[j] = sj;
     }
     // the cavity records, once (the no-mass loop evaluates Cavity::u_value every pass: surface.rs:814)
@@ -618,8 +631,22 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     const bool single = kSingleLane && is_first && is_last;
     const bool my_back = !is_first;
     const int sidx = (my_back ? S : 0) + d;
+    // Every load of the tile is issued here, from addresses that depend on the tile descriptor alone: a record that
+    // names another record (the second side of a one-lane wall, the front side behind a back / Ambient one) would put
+    // a memory round trip of its own in front of the tile — the streamed kernels are bound by exactly that chain.
     const SideConst c_load = sd.sc[sidx];
     const SideDyn dy_load = sd.dyn[sidx];
+    SideConst cb2 = c_load;
+    SideDyn db2 = dy_load;
+    if constexpr (kSingleLane) {
+        // (uniform tiles: a one-lane tile is one for every lane — a scalar branch, nothing waits for it)
+        if ((!mixed && k == 1) || single) {  // this lane is also the last one of its surface
+            cb2 = sd.sc[S + d];
+            db2 = sd.dyn[S + d];
+        }
+    }
+    int4 cavref = make_int4(-1, -1, -1, -1);
+    if constexpr (CAV) cavref = reinterpret_cast<const int4 *>(na.cavref)[d];
     const int kind_n_mine = c_load.kind_n;
     // streamed: a Space-facing side's place in its zone's contribution list waits in LDS for the end of the tile (in
     // two registers across the RK stages it costs the 16-node variant its second wavefront per SIMD; fetched again
@@ -633,6 +660,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         if constexpr (kSingleLane) b_lz = single ? fa.side_lzone[S + d] : 0;
     }
     (void)b_lz;
+    // FUSED: block-local zone of the FRONT side behind this back side (a back / Ambient side reads t_front, below)
+    int peer_lz = 0;
+    if constexpr (FUSED) peer_lz = fa.side_lzone[d];
+    (void)peer_lz;
 
     // ---- node data: T, V = dt/C, U (coalesced 16-byte loads) ----
     double T[M], V[M], U[M];
@@ -646,7 +677,15 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * pstride);
             double2 *sp2 = reinterpret_cast<double2 *>(sp);
             const int n2 = G * (pstride / 2);
-            for (int i = lane; i < n2; i += kWave) sp2[i] = gp[i];
+            // (six loads in flight, then six LDS writes: a load-wait-write loop costs a memory round trip per pass)
+            for (int i0 = 0; i0 < n2; i0 += 6 * kWave) {
+                double2 t6[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) t6[q] = gp[min(i0 + q * kWave + lane, n2 - 1)];
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (i0 + q * kWave + lane < n2) sp2[i0 + q * kWave + lane] = t6[q];
+            }
         }
         {
             const unsigned char *pc = na.cls + tile.node_base + (int64_t)ll * M;
@@ -713,17 +752,16 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     };
 
     // does any back side of this tile face an ambient temperature? (wave-uniform)
+    // (the other side's kind travels in every record: bits 4-5 of kind_n)
     const bool wave_quirk = __any((is_last && (kind_n_mine & 3) == KIND_AMBIENT && my_back) ||
-                                  (single && (sd.sc[S + d].kind_n & 3) == KIND_AMBIENT));
-    int4 cavref = make_int4(-1, -1, -1, -1);
-    if constexpr (CAV) cavref = reinterpret_cast<const int4 *>(na.cavref)[d];
-    SideConst cb2 = c_load;
-    SideDyn db2 = dy_load;
-    if constexpr (kSingleLane) {
-        if (single) {  // this lane is also the last one of its surface
-            cb2 = sd.sc[S + d];
-            db2 = sd.dyn[S + d];
-        }
+                                  (single && ((kind_n_mine >> 4) & 3) == KIND_AMBIENT));
+    // streamed: the zone temperatures of this lane's side(s), gathered as soon as the records are here — for every
+    // lane (SideConst::zone is always a valid index), so that no branch sits between the records and the gather
+    double zt_mine = 0.0, zt_b2 = 0.0;
+    (void)zt_mine; (void)zt_b2;
+    if constexpr (!FUSED) {
+        zt_mine = zone_T[c_load.zone];
+        if constexpr (kSingleLane) zt_b2 = zone_T[cb2.zone];
     }
 
     // V = dt/C of local node j: registers, or the workgroup's LDS array (FUSED with 16 nodes per lane)
@@ -757,11 +795,12 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     const SideConst c = c_cur;
     const SideDyn dy = dy_cur;
     // get_boundary_temperature, model.rs:79-96 (FUSED: zone temperatures live in LDS)
-    auto btemp = [&](const SideConst &cc, int lz) -> double {
+    // zt: the gathered temperature of cc.zone (streamed)
+    auto btemp = [&](const SideConst &cc, int lz, double zt) -> double {
         const int kind = cc.kind_n & 3;
         if (kind == KIND_SPACE) {
             if constexpr (FUSED) return s_zT[lz];
-            else return zone_T[cc.zone];
+            else return zt;
         }
         if (kind == KIND_AMBIENT) return cc.ambient;
         return w.t_out;
@@ -772,10 +811,10 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     // boundary temperature, radiant temperature, forced convection term, and whether the side reads the
     // FRONT surface temperature (back/Ambient takes t_front and the front temperature, surface.rs:672-686).
     // Kept in plain scalars (a struct here ends up in scratch memory).
-    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, int lz, double &air_t,
+    auto prepare = [&](const SideConst &cc, const SideDyn &dd, bool back, int rec, int lz, double zt, double &air_t,
                        double &rad_t, double &forced, bool &use_front_T) {
         const int kind = cc.kind_n & 3;
-        air_t = btemp(cc, lz);
+        air_t = btemp(cc, lz, zt);
         rad_t = air_t;
         use_front_T = false;
         forced = 0.0;
@@ -784,12 +823,20 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             forced = (windward ? 1.0 : 0.5) * (cc.forced * w.sqrt_ws);  // convection.rs:161-163
             rad_t = dd.rad_t;                                            // surface.rs:647,692
         } else if (back && kind == KIND_AMBIENT) {
-            const SideConst fc = sd.sc[rec - S];
-            int flz = 0;
-            if constexpr (FUSED) flz = fa.side_lzone[rec - S];
-            rad_t = btemp(fc, flz);
+            // t_front (surface.rs:672-686): the front side's boundary source travels in this record (layout.hpp) —
+            // its kind in bits 4-5, its zone in `zone` (whose temperature is zt), its ambient temperature in `forced`
+            const int fkind = (cc.kind_n >> 4) & 3;
+            if (fkind == KIND_SPACE) {
+                if constexpr (FUSED) rad_t = s_zT[peer_lz];
+                else rad_t = zt;
+            } else if (fkind == KIND_AMBIENT) {
+                rad_t = cc.forced;
+            } else {
+                rad_t = w.t_out;
+            }
             use_front_T = true;
         }
+        (void)rec;
     };
     // (the debug override of a side, surface.rs:708-714, is read where it is applied — a uniform branch on a
     // pointer that is null in production — instead of living in two registers across the RK stages)
@@ -898,7 +945,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
 
     double my_air, my_rad, my_forced;
     bool my_useF;
-    prepare(c, dy, my_back, sidx, my_lz, my_air, my_rad, my_forced, my_useF);
+    prepare(c, dy, my_back, sidx, my_lz, zt_mine, my_air, my_rad, my_forced, my_useF);
     if (is_first || is_last) {
         double h_, q_;
         add_face(c, dy, my_back, my_air, my_rad, my_forced, sidx, my_useF, h_, q_);
@@ -912,7 +959,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     if constexpr (kSingleLane) {
         if (single) {  // this lane is also the last one of its surface
             double b_rad;
-            prepare(cb2, db2, true, S + d, b_lz, b_air, b_rad, b_forced, b_useF);
+            prepare(cb2, db2, true, S + d, b_lz, zt_b2, b_air, b_rad, b_forced, b_useF);
             b_cos = cb2.cos_eff;
             b_neg = cb2.alpha;
             add_face(cb2, db2, true, b_air, b_rad, b_forced, S + d, b_useF, hB, qB);
@@ -1288,10 +1335,12 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
     const FusedArgs fa{};
     if (wave0 >= n_tiles) return;
     constexpr int kNm = VARIANT == kStreamChunks ? 2 : 1;
-    // (the tile descriptor is wave-uniform: scalar loads)
+    // (the tile descriptor is wave-uniform: scalar loads; the next one is fetched a whole tile ahead of its use)
+    FastTile tile_next = tiles[__builtin_amdgcn_readfirstlane(wave0)];
     for (int wv = wave0; wv < n_tiles; wv += n_waves) {
         const int w = __builtin_amdgcn_readfirstlane(wv);
-        FastTile tile = tiles[w];
+        FastTile tile = tile_next;
+        tile_next = tiles[__builtin_amdgcn_readfirstlane(min(wv + n_waves, n_tiles - 1))];
         const int kind = (tile.k >> kTileKindShift) & 3;
         const bool nm = (tile.k & kTileNmBit) != 0;
         tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit | kTileChunkyBit));

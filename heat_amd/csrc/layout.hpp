@@ -62,8 +62,12 @@ struct GeneralTile {
 // Constants of one side (64 bytes).
 struct alignas(16) SideConst {
     int32_t kind_n;   // bits 0-1: boundary kind; bit 2: always windward (|cos tilt| >= 0.98,
-                      // reference src/surface.rs:38); bits 16-31: node count of the surface
-    int32_t zone;     // zone index when kind == KIND_SPACE
+                      // reference src/surface.rs:38); bits 4-5: kind of the surface's OTHER side; bits 16-31: node
+                      // count of the surface
+    int32_t zone;     // zone index when kind == KIND_SPACE; always a valid index (0 otherwise: the kernels gather the
+                      // zone temperature unconditionally). A BACK side of kind KIND_AMBIENT carries the front side's
+                      // boundary source here (zone) and in `forced` (ambient temperature): surface.rs:672-686 takes
+                      // t_front for its radiant temperature
     double ambient;   // kind == KIND_AMBIENT: Boundary::AmbientTemperature { temperature };
                       // kind == KIND_SPACE: the bits of an int64 — this side's position in the zone contribution
                       // list (ZoneEntry / SideArrays::zc), see side_entry_pos()

@@ -813,7 +813,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         for (int side = 0; side < 2; side++) {
             SideConst c;
             const int kind = side ? d->back_kind[s] : d->front_kind[s];
-            c.kind_n = kind | always_windward | (n << 16);
+            const int peer = side ? d->front_kind[s] : d->back_kind[s];  // the surface's other side (layout.hpp)
+            c.kind_n = kind | always_windward | ((peer & 3) << 4) | (n << 16);
             c.zone = kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : 0;
             c.ambient = side ? d->back_ambient[s] : d->front_ambient[s];
             c.emis = side ? d->back_emissivity[s] : d->front_emissivity[s];
@@ -836,6 +837,13 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 c.alpha = neg;
             }
             c.forced = kind == HEAT_BOUNDARY_OUTDOOR ? forced : 0.0;
+            if (side == 1 && kind == HEAT_BOUNDARY_AMBIENT) {
+                // A back side facing an ambient temperature takes t_front for its radiant temperature
+                // (surface.rs:672-686): the FRONT side's boundary source travels in this record's unused slots, so that
+                // the kernels need no second record (a dependent load in front of every tile that holds such a wall)
+                if (peer == HEAT_BOUNDARY_SPACE) c.zone = d->front_zone[s];
+                if (peer == HEAT_BOUNDARY_AMBIENT) c.forced = d->front_ambient[s];
+            }
             c.nx = d->normal_x[s];
             c.ny = d->normal_y[s];
             hSide[(int64_t)side * S + dd] = c;
@@ -1135,6 +1143,8 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
         const int n = (int)(d->node_offset[s + 1] - d->node_offset[s]);
         PLAN_REQUIRE(p.meta[dd] == n && (p.side[dd].kind_n >> 16) == n && (p.side[S + dd].kind_n >> 16) == n, "node count of device surface %lld", (long long)dd);
         PLAN_REQUIRE((p.side[dd].kind_n & 3) == d->front_kind[s] && (p.side[S + dd].kind_n & 3) == d->back_kind[s], "boundary kinds of device surface %lld", (long long)dd);
+        PLAN_REQUIRE(((p.side[dd].kind_n >> 4) & 3) == d->back_kind[s] && ((p.side[S + dd].kind_n >> 4) & 3) == d->front_kind[s], "peer kinds of device surface %lld", (long long)dd);
+        PLAN_REQUIRE(p.side[dd].zone >= 0 && p.side[S + dd].zone >= 0 && (p.n_zones == 0 || (p.side[dd].zone < p.n_zones && p.side[S + dd].zone < p.n_zones)), "zone fields of device surface %lld (read unconditionally)", (long long)dd);
     }
     // zone contribution lists: one entry per Space-facing side, each side knows its place
     PLAN_REQUIRE((int64_t)p.zone_off.size() == Z + 1 && p.zone_off[0] == 0, "zone offsets");
