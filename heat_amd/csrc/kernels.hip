@@ -182,13 +182,42 @@ __device__ __forceinline__ void rk4_horner(double (&T)[M], VF V, const double (&
 // group, reference operation order (march_nomass, surface.rs:790-898), no FMA contraction.
 #pragma clang fp contract(off)
 constexpr int kSmallNodes = 4;
+// The node temperatures of a small surface as four scalars. (As `double T[4]` the array stays in memory — LDS, or
+// scratch inside k_surfaces_stream: the compiler turns the select chain that picks the last node into an indexed load
+// — and every pass of the no-mass loop then waits for a memory round trip.) j is a constant after unrolling.
+__device__ __forceinline__ double opaque_select(bool cond, double x, double y) {  // cond ? x : y
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(cond);
+    int lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(y)), "v"(__double2loint(x)), "s"(m));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(y)), "v"(__double2hiint(x)), "s"(m));
+    return __hiloint2double(hi, lo);
+}
+struct Nodes4 {
+    double a, b, c, d;
+    __device__ __forceinline__ double get(int j) const { return j == 0 ? +a : (j == 1 ? +b : (j == 2 ? +c : +d)); }
+    __device__ __forceinline__ void set(int j, double v) {
+        if (j == 0) a = v;
+        else if (j == 1) b = v;
+        else if (j == 2) c = v;
+        else d = v;
+    }
+    __device__ __forceinline__ double last(int nn) const {  // node nn - 1
+        // (selects the optimizer cannot see through: it turns a plain select chain over a, b, c, d into a load indexed
+        // by nn - 1, which keeps the four values in memory)
+        double r = a;
+        r = opaque_select(nn == 2, b, r);
+        r = opaque_select(nn == 3, c, r);
+        r = opaque_select(nn == 4, d, r);
+        return r;
+    }
+};
 
 // One sub-timestep of one small surface: calc_border_conditions, march_nomass on the chunk (0, nn), the
 // coefficients and flows with the new temperatures (model.rs:150-169). T is updated in place.
 template <int CAV>
 __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst &cb, const SideDyn &df, const SideDyn &db,
                                            const double *__restrict__ hs_fix, int d, int S, const StepWeather &w,
-                                           double t_front_b, double t_back_b, int nn, double (&T)[kSmallNodes],
+                                           double t_front_b, double t_back_b, int nn, Nodes4 &T,
                                            const double (&Us)[kSmallNodes], const double (&sol)[kSmallNodes],
                                            const int (&cav)[kSmallNodes], const CavityDev (&cv)[kSmallNodes - 1], int &bad,
                                            unsigned int &iters, SideOut &of, SideOut &ob) {
@@ -197,10 +226,10 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
     auto last = [&](const double (&x)[NS]) {
         double r = x[0];
 #pragma unroll
-        for (int j = 1; j < NS; j++) r = (j == nn - 1) ? x[j] : r;
+        for (int j = 1; j < NS; j++) r = (j == nn - 1) ? +x[j] : +r;
         return r;
     };
-    const double T0 = T[0], Tn = last(T);
+    const double T0 = T.a, Tn = T.last(nn);
     const bool quirk = (bk == KIND_AMBIENT);
     double f_hs, f_rad, b_hs, b_rad;
     const double f_surf = T0, b_surf = quirk ? T0 : Tn;
@@ -227,7 +256,7 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
             if (j < nn - 1) {
                 double u = Us[j];
                 if constexpr (CAV) {
-                    if (cav[j] >= 0) u = cavity_u_value(cv[j], T[j], T[j + 1], bad);
+                    if (cav[j] >= 0) u = cavity_u_value(cv[j], T.get(j), T.get(j + 1), bad);
                 }
                 dg[j] += -u;
                 dg[j + 1] = dg[j + 1] - u;
@@ -235,9 +264,9 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
                 lo[j + 1] = lo[j + 1] + u;
             }
         }
-        q[0] += t_front_b * f_hs + f_radhs * (f_rad - T[0]);
+        q[0] += t_front_b * f_hs + f_radhs * (f_rad - T.a);
         dg[0] += -f_hs;
-        const double bq = t_back_b * b_hs + b_radhs * (b_rad - last(T));
+        const double bq = t_back_b * b_hs + b_radhs * (b_rad - T.last(nn));
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             if (j == nn - 1) { q[j] += bq; dg[j] += -b_hs; }
@@ -263,11 +292,11 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
         }
         double err = 0.0;
 #pragma unroll
-        for (int j = 0; j < NS; j++) if (j < nn) err += fabs(x[j] - T[j]);
+        for (int j = 0; j < NS; j++) if (j < nn) err += fabs(x[j] - T.get(j));
         if (err > old_err) break;                            // surface.rs:842-848
         if (err != err) { bad |= FLAG_NAN_NOMASS; break; }   // surface.rs:850
 #pragma unroll
-        for (int j = 0; j < NS; j++) if (j < nn) T[j] = (T[j] + x[j]) * 0.5;
+        for (int j = 0; j < NS; j++) if (j < nn) T.set(j, (T.get(j) + x[j]) * 0.5);
         const double tol = (count < 100) ? 0.01 : 0.5;      // surface.rs:885
         if (err / (double)nn < tol) break;
         old_err = err;
@@ -275,7 +304,7 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
     }
 
     {   // outputs with the new surface temperatures (model.rs:150-169)
-        const double T0n = T[0], Tnn = last(T);
+        const double T0n = T.a, Tnn = T.last(nn);
         double fh, bh, r_;
         eval_side(cf, w, t_front_b, t_front_b, df.rad_t, T0n, fh, r_, bad);
         eval_side(cb, w, t_back_b, t_back_b, db.rad_t, quirk ? T0n : Tnn, bh, r_, bad);
@@ -293,7 +322,7 @@ __device__ __forceinline__ void small_step(const SideConst &cf, const SideConst 
 // A small surface's constants and state, fetched once (the general layout: node j of lane l at node_base + j * 64 + l).
 template <int CAV>
 __device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, const NodeArrays &na, int64_t gen_base,
-                                           const SideDyn &df, const SideDyn &db, int nn, double (&T)[kSmallNodes],
+                                           const SideDyn &df, const SideDyn &db, int nn, Nodes4 &T,
                                            double (&Us)[kSmallNodes], double (&sol)[kSmallNodes], int (&cav)[kSmallNodes],
                                            CavityDev (&cv)[kSmallNodes - 1]) {
     const double *Tg = na.T + tile.node_base + lane;
@@ -315,7 +344,7 @@ __device__ __forceinline__ void small_load(const GeneralTile &tile, int lane, co
 #pragma unroll
     for (int j = 0; j < kSmallNodes; j++) {
         const bool v = j < nn;
-        T[j] = v ? tl[j] : 0.0;
+        T.set(j, v ? tl[j] : 0.0);
         Us[j] = v ? ul[j] : 0.0;
         cav[j] = (CAV && v) ? cl[j] : -1;
         // surface.rs:930-931
@@ -352,7 +381,8 @@ __device__ __forceinline__ unsigned int small_tile_march(int64_t node_base, int 
     const SideDyn df = sd.dyn[d];
     const SideDyn db = sd.dyn[S + d];
     const int nn = cf.kind_n >> 16;
-    double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
+    Nodes4 T{0.0, 0.0, 0.0, 0.0};
+    double Us[kSmallNodes], sol[kSmallNodes];
     int cav[kSmallNodes];
     CavityDev cv[kSmallNodes - 1];
     small_load<CAV>(tile, lane, na, gen_base, df, db, nn, T, Us, sol, cav, cv);
@@ -363,14 +393,12 @@ __device__ __forceinline__ unsigned int small_tile_march(int64_t node_base, int 
                     boundary_temperature(cb, w, zone_T), nn, T, Us, sol, cav, cv, bad, iters, of, ob);
     double *Tg = na.T + node_base + lane;
 #pragma unroll
-    for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
+    for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T.get(j);
     sd.out[d] = of;
     sd.out[S + d] = ob;
     {
-        double Tl = T[0];
-#pragma unroll
-        for (int j = 1; j < kSmallNodes; j++) Tl = (j == nn - 1) ? T[j] : Tl;
-        put_zone_contrib(sd, cf, of.hs, T[0]);
+        const double Tl = T.last(nn);
+        put_zone_contrib(sd, cf, of.hs, T.a);
         put_zone_contrib(sd, cb, ob.hs, Tl);
     }
     if (bad) report_failure(flags, bad, (unsigned int)d);
@@ -508,7 +536,8 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
     const int nn = cf.kind_n >> 16;
     const int lz_f = fa.side_lzone[d], lz_b = fa.side_lzone[S + d];
     const double area = fa.side_area[d];
-    double T[kSmallNodes], Us[kSmallNodes], sol[kSmallNodes];
+    Nodes4 T{0.0, 0.0, 0.0, 0.0};
+    double Us[kSmallNodes], sol[kSmallNodes];
     int cav[kSmallNodes];
     CavityDev cv[kSmallNodes - 1];
     small_load<1>(tile, active ? lane : 0, na, fa.gen_base, df, db, nn, T, Us, sol, cav, cv);
@@ -530,10 +559,8 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
                       cv, bad, iters, of, ob);
         if (active) {
             bad_all |= bad;
-            double Tl = T[0];
-#pragma unroll
-            for (int j = 1; j < kSmallNodes; j++) Tl = (j == nn - 1) ? T[j] : Tl;
-            if ((cf.kind_n & 3) == KIND_SPACE) l.hT[l.slots[wib * kWave + lane]] = make_double2(of.hs * area, T[0]);
+            const double Tl = T.last(nn);
+            if ((cf.kind_n & 3) == KIND_SPACE) l.hT[l.slots[wib * kWave + lane]] = make_double2(of.hs * area, T.a);
             if ((cb.kind_n & 3) == KIND_SPACE) l.hT[l.slots[lanes_per_side + wib * kWave + lane]] = make_double2(ob.hs * area, Tl);
         }
         fused_zone_phase(blk, fa, l, wib, n_waves, lane, bad_all);
@@ -542,7 +569,7 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
     if (active) {
         double *Tg = na.T + tile.node_base + lane;
 #pragma unroll
-        for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T[j];
+        for (int j = 0; j < kSmallNodes; j++) if (j < nn) Tg[(int64_t)j * kWave] = T.get(j);
         sd.out[d] = of;
         sd.out[S + d] = ob;
         if (fa.small_iters) fa.small_iters[(int64_t)tile_index * kWave + lane] += iters;
@@ -746,7 +773,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         double r = x[M - 1];
         if (!full) {
 #pragma unroll
-            for (int j = 0; j < M - 1; j++) r = (j == jl) ? x[j] : r;
+            for (int j = 0; j < M - 1; j++) r = (j == jl) ? +x[j] : +r;
         }
         return r;
     };
@@ -904,8 +931,8 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                     double up = UL, tp = T_prev_last;
 #pragma unroll
                     for (int j = 1; j < M; j++) {
-                        up = (j == jl) ? U[j - 1] : up;
-                        tp = (j == jl) ? T[j - 1] : tp;
+                        up = (j == jl) ? +U[j - 1] : +up;
+                        tp = (j == jl) ? +T[j - 1] : +tp;
                     }
                     u_in = up;
                     t_in = tp;
@@ -995,13 +1022,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                 double ta = T[0], tb = T[0], tp = T_prev_last, tn = T_next_first, up = UL, ui = 0.0, un = 0.0;
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    ta = (j == j0) ? T[j] : ta;
-                    tb = (j == j1) ? T[j] : tb;
-                    if (j + 1 < M) tp = (j + 1 == j0) ? T[j] : tp;
-                    if (j > 0) tn = (j == j1 + 1) ? T[j] : tn;
-                    if (j + 1 < M) up = (j + 1 == j0) ? U[j] : up;
-                    ui = (j == j0) ? U[j] : ui;
-                    un = (j == j1) ? U[j] : un;
+                    ta = (j == j0) ? +T[j] : +ta;
+                    tb = (j == j1) ? +T[j] : +tb;
+                    if (j + 1 < M) tp = (j + 1 == j0) ? +T[j] : +tp;
+                    if (j > 0) tn = (j == j1 + 1) ? +T[j] : +tn;
+                    if (j + 1 < M) up = (j + 1 == j0) ? +U[j] : +up;
+                    ui = (j == j0) ? +U[j] : +ui;
+                    un = (j == j1) ? +U[j] : +un;
                 }
                 const bool faceL = is_first && j0 == 0;           // the chunk starts at the front face
                 const bool faceR = is_last && j1 == jl;           // ... ends at the back face
@@ -1065,8 +1092,8 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                 double ta = T[0], tb = T_next_first;
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    ta = (j == jc) ? T[j] : ta;
-                    if (j + 1 < M) tb = (j == jc) ? T[j + 1] : tb;
+                    ta = (j == jc) ? +T[j] : +ta;
+                    if (j + 1 < M) tb = (j == jc) ? +T[j + 1] : +tb;
                 }
                 const double u = cavity_u_value(na.cavs[cidx], ta, tb, bad);
 #pragma unroll
