@@ -200,6 +200,7 @@ struct heat_batch {
     bool class_has_chunks[kNumFast] = {};  // the class holds tiles with such chunks: its own launch takes the NM = 2 variant
     bool in_ulist[2][kNumFast] = {};
     bool small_in_ulist[2] = {false, false};
+    bool smallcav_in_ulist[2] = {false, false};  // the double glazing (small surfaces with a gas cavity) as well
     DevBuf<unsigned long long> d_ucount;  // no-mass pass counters of the unified lists: [list][tile]
     size_t ucount_stride = 0;
     int n_gen_tiles = 0;    // tiles in the general layout: [0, n_small_tiles) small, the rest catch-all
@@ -540,13 +541,57 @@ int select_device(heat_batch *b) {
     return HEAT_OK;
 }
 
+// A persistent wavefront w of a k_surfaces_stream launch walks tiles[w], tiles[w + n_waves], ... — round after round. The
+// tiles of a part differ in length by an order of magnitude (a window whose no-mass loop re-evaluates its gas cavity
+// every pass against eight massive nodes per lane), so the list is laid out in rounds such that every wavefront's share
+// takes about the same time: longest-processing-time-first over the wavefronts, each wavefront's tiles longest first,
+// empty tiles (G = 0: a wavefront skips them at once) where a wavefront has fewer tiles than rounds.
+std::vector<FastTile> balanced_rounds(const std::vector<FastTile> &tiles, const std::vector<float> &cost, int n_waves) {
+    const size_t n = tiles.size();
+    if (n_waves <= 0 || n <= (size_t)n_waves) return tiles;  // a tile per wavefront at most: nothing to balance
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[a] > cost[b]; });
+    // least-loaded wavefront first (a binary heap of (load, wavefront))
+    std::vector<std::pair<float, int32_t>> heap(n_waves);
+    for (int w = 0; w < n_waves; w++) heap[w] = {0.f, w};
+    auto later = [](const std::pair<float, int32_t> &a, const std::pair<float, int32_t> &b) {
+        return a.first > b.first || (a.first == b.first && a.second > b.second);
+    };
+    std::make_heap(heap.begin(), heap.end(), later);
+    std::vector<std::vector<int32_t>> mine(n_waves);
+    for (int32_t t : order) {
+        std::pop_heap(heap.begin(), heap.end(), later);
+        auto &top = heap.back();
+        mine[top.second].push_back(t);
+        top.first += cost[t];
+        std::push_heap(heap.begin(), heap.end(), later);
+    }
+    size_t rounds = 0;
+    for (const auto &m : mine) rounds = std::max(rounds, m.size());
+    FastTile empty;
+    empty.node_base = 0;
+    empty.surf_base = 0;
+    empty.k = (int16_t)(kStreamKindSmall << kStreamKindShift);  // (a small tile of no surface: every lane leaves at once)
+    empty.G = 0;
+    std::vector<FastTile> out(rounds * (size_t)n_waves, empty);
+    for (int w = 0; w < n_waves; w++)
+        for (size_t r = 0; r < mine[w].size(); r++) out[r * (size_t)n_waves + w] = tiles[mine[w][r]];
+    return out;
+}
+
 // The unified streamed tile lists from the current per-class lists (create time, and again when
 // heat_batch_set_shared_zones has moved tiles between the fused workgroups and the streamed part).
 int rebuild_unified(heat_batch *b) {
     static const bool off = getenv("HEAT_AMD_NO_UNIFIED") != nullptr;  // measurement: one launch per class as before
-    auto eligible = [](int c) { return kFastPAL[c] && !kFastCAV[c] && !(kFastM[c] == 16 && kFastNM[c]); };
-    size_t cap = (size_t)b->n_small_plain_tiles;
+    // (16 nodes per lane with facings or cavities keep launches of their own: one wavefront per SIMD)
+    auto eligible = [](int c) { return kFastPAL[c] && !(kFastM[c] == 16 && (kFastNM[c] || kFastCAV[c])); };
+    static const bool cav_off = getenv("HEAT_AMD_NO_UNIFIED_CAV") != nullptr;  // measurement: round 2's two launches
+    size_t cap = (size_t)b->n_small_tiles;
     for (int c = 0; c < kNumFast; c++) if (eligible(c)) cap += b->h_tiles_cur[c].size();
+    // (the balanced parts are padded to whole rounds: two rounds more than the tiles need, per part, bound the padding)
+    const int waves_light = b->n_cu * 3 * 4, waves_cav = b->n_cu * 2 * 4;  // persistent grids of the light / cavity variants
+    cap += 2 * (size_t)(waves_light + waves_cav) + 2 * (size_t)(waves_light + waves_cav);
     if (b->d_ucount.n == 0) {
         b->ucount_stride = std::max<size_t>(cap, 1);
         HIP_TRY(b->d_ucount.zeros(2 * b->ucount_stride));
@@ -557,12 +602,33 @@ int rebuild_unified(heat_batch *b) {
         for (const FastTile &ft : b->h_tiles_cur[c]) b->class_has_chunks[c] = b->class_has_chunks[c] || (ft.k & kTileChunkyBit) != 0;
     }
     for (int v = 0; v < 2; v++) {
-        // the three parts (kernels.hip, k_surfaces_stream): wide | light | chunks
+        // the four parts (kernels.hip, k_surfaces_stream): wide | light | chunks | cavities
         std::vector<FastTile> part[kStreamVariants];
-        int n_classes = 0;
+        int n_classes = 0, n_cav_classes = 0;
+        // double glazing: the streamed small tiles with cavities ([plain | streamed with cavities | fused workgroups' ...])
+        const int nsc = cav_off ? 0 : (v ? b->n_small_tiles - b->n_small_plain_tiles : b->n_smallcav_stream_tiles);
+        for (int j = 0; j < nsc; j++) {  // (first in their part: the longest tiles)
+            const GeneralTile &g = b->h_gen_tiles_cur[b->n_small_plain_tiles + j];
+            FastTile ft;
+            ft.node_base = g.node_base;
+            ft.surf_base = g.surf_base;
+            ft.k = (int16_t)(kStreamKindSmall << kStreamKindShift);
+            ft.G = (int16_t)g.G;
+            part[3].push_back(ft);
+        }
         for (int mi = 2; mi >= 0; mi--)  // 16 nodes per lane first: the heaviest tiles lead
             for (int c = mi * 6; c < mi * 6 + 6; c++) {
-                if (!eligible(c)) continue;
+                if (!eligible(c) || (kFastCAV[c] && cav_off)) continue;
+                if (kFastCAV[c]) {
+                    const int n = v ? b->n_fast_tiles[c] : b->n_stream_tiles[c];
+                    n_cav_classes += n > 0;
+                    for (int t = 0; t < n; t++) {
+                        FastTile ft = b->h_tiles_cur[c][t];
+                        ft.k = (int16_t)((ft.k & (0x1ff | kTileMixedBit | kTileChunkyBit)) | (mi << kStreamKindShift) | (kFastNM[c] ? kStreamNmBit : 0));
+                        part[3].push_back(ft);
+                    }
+                    continue;
+                }
                 const int n = v ? b->n_fast_tiles[c] : b->n_stream_tiles[c];
                 n_classes += n > 0;
                 for (int t = 0; t < n; t++) {
@@ -574,34 +640,43 @@ int rebuild_unified(heat_batch *b) {
             }
         // worth it when it replaces two launches or more (a class on its own keeps its own persistent kernel)
         const bool use = !off && (n_classes + (ns > 0)) >= 2;
+        // ... and the cavity part when it replaces two launches (glazing + walls with cavities, or two such classes)
+        const bool use_cav = !off && !cav_off && (n_cav_classes + (nsc > 0)) >= 2;
         b->n_ulist[v] = 0;
-        for (int c = 0; c < kNumFast; c++) b->in_ulist[v][c] = use && eligible(c);
+        for (int c = 0; c < kNumFast; c++) b->in_ulist[v][c] = eligible(c) && (kFastCAV[c] ? use_cav : use);
         b->small_in_ulist[v] = use && ns > 0;
+        b->smallcav_in_ulist[v] = use_cav && nsc > 0;
         for (int q = 0; q < kStreamVariants; q++) b->ulist_part[v][q][0] = b->ulist_part[v][q][1] = 0;
-        if (!use) continue;
-        // the latency-bound small tiles are spread evenly through the light part
-        {
-            const std::vector<FastTile> fast = part[1];
-            const size_t N = fast.size() + (size_t)ns;
-            std::vector<FastTile> list(N);
-            std::vector<uint8_t> taken(N, 0);
+        if (!use) part[0].clear(), part[1].clear(), part[2].clear();
+        if (!use_cav) part[3].clear();
+        if (!use && !use_cav) continue;
+        // Relative tile times (measured on MI355X, 1 M ragged walls / 100 k windows + 100 k Trombe walls; only their
+        // ratios matter): a tile of eight massive nodes per lane 1, with facings 2, four nodes per lane 0.7 / 1.4, a tile
+        // of small surfaces 3, of double glazing 12, a tile of walls with cavities 2.5.
+        static const bool balance_off = getenv("HEAT_AMD_NO_BALANCE") != nullptr;  // measurement
+        auto tile_cost = [&](const FastTile &ft, bool cav) -> float {
+            const int kind = (ft.k >> kStreamKindShift) & 3;
+            if (kind == kStreamKindSmall) return cav ? 12.f : 3.f;
+            const float base = kind == 1 ? 1.f : 0.7f;
+            if (cav) return 2.5f * base;
+            return (ft.k & kStreamNmBit) ? 2.f * base : base;
+        };
+        if (use) {  // the small surfaces join the light part
             for (int j = 0; j < ns; j++) {
-                size_t pos = (size_t)(((double)j + 0.5) * (double)N / (double)ns);
-                if (pos >= N) pos = N - 1;
-                while (taken[pos]) pos = (pos + 1) % N;
                 const GeneralTile &g = b->h_gen_tiles_cur[j];
                 FastTile ft;
                 ft.node_base = g.node_base;
                 ft.surf_base = g.surf_base;
                 ft.k = (int16_t)(kStreamKindSmall << kStreamKindShift);
                 ft.G = (int16_t)g.G;
-                list[pos] = ft;
-                taken[pos] = 1;
+                part[1].push_back(ft);
             }
-            size_t q = 0;
-            for (size_t pos = 0; pos < N; pos++)
-                if (!taken[pos]) list[pos] = fast[q++];
-            part[1] = list;
+        }
+        for (int q : {1, 3}) {
+            if (balance_off || part[q].empty()) continue;
+            std::vector<float> cost(part[q].size());
+            for (size_t t = 0; t < part[q].size(); t++) cost[t] = tile_cost(part[q][t], q == 3);
+            part[q] = balanced_rounds(part[q], cost, q == 1 ? waves_light : waves_cav);
         }
         std::vector<FastTile> all;
         for (int q = 0; q < kStreamVariants; q++) {
@@ -636,7 +711,8 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     int n_launch = 0;
     for (int c = 0; c < kNumFast; c++) n_launch += nt[c] > 0;
     // small tiles with cavities: the streamed ones come first, the fused workgroups' after them
-    const int n_cav_tiles = streamed_only ? b->n_smallcav_stream_tiles : b->n_small_tiles - b->n_small_plain_tiles;
+    int n_cav_tiles = streamed_only ? b->n_smallcav_stream_tiles : b->n_small_tiles - b->n_small_plain_tiles;
+    if (unified && b->smallcav_in_ulist[ul]) n_cav_tiles = 0;
     n_launch += unified;
     n_launch += n_small_plain > 0;
     n_launch += n_cav_tiles > 0;
@@ -660,7 +736,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         hipStream_t us = next_stream();
         // the light part first: its wavefronts are the latency-bound ones, the wide part's tail is the shorter
         static const int order_env = getenv("HEAT_AMD_STREAM_ORDER") ? atoi(getenv("HEAT_AMD_STREAM_ORDER")) : 0;  // measurement
-        const int seq[2][kStreamVariants] = {{1, 2, 0}, {0, 1, 2}};
+        const int seq[2][kStreamVariants] = {{3, 1, 2, 0}, {0, 1, 2, 3}};
         for (int qi = 0; qi < kStreamVariants; qi++) {
             const int q = seq[order_env ? 1 : 0][qi];
             const int first = b->ulist_part[ul][q][0], n = b->ulist_part[ul][q][1];

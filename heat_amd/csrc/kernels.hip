@@ -1340,9 +1340,14 @@ constexpr int kTileNmBit = 1 << 11;
 //                 per SIMD (<= 168 registers)
 //   kStreamChunks tiles of 8 / 4 nodes per lane that hold other no-mass chunks (inside the wall, of two nodes): the
 //                 chunk loop's registers, 2 wavefronts per SIMD
+//   kStreamCav    everything with a gas cavity that takes 8 / 4 nodes per lane or one lane per surface: double glazing
+//                 (small surfaces whose no-mass loop re-evaluates Cavity::u_value every pass, surface.rs:814) and walls
+//                 with cavities between massive nodes (Trombe walls) — both bound by the latency of the Nusselt
+//                 correlations' transcendental chains; in ONE launch (the windows first: theirs are the longest tiles)
+//                 instead of two on forked streams, whose fork and join cost more than either kernel's tail
 // The host sorts a batch's tiles into one list per variant (batch.hip, rebuild_unified) and launches them back to
 // back on the batch's stream.
-enum { kStreamWide = 0, kStreamLight = 1, kStreamChunks = 2 };
+enum { kStreamWide = 0, kStreamLight = 1, kStreamChunks = 2, kStreamCav = 3 };
 template <int VARIANT>
 __global__ void __launch_bounds__(256, VARIANT == kStreamLight ? 3 : 2)
 k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base, SideArrays sd,
@@ -1375,18 +1380,19 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
             fast_tile_march<16, 0, 1, 0, 0>(tile, w, false, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
                                             zone_T, flags, nomass_iters, fa, write_out);
         } else {
+            constexpr int kCav = VARIANT == kStreamCav ? 1 : 0;
             switch (kind) {
             case 1:
-                fast_tile_march<8, kNm, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
-                                                 zone_T, flags, nomass_iters, fa, write_out);
+                fast_tile_march<8, kNm, 1, kCav, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
+                                                    zone_T, flags, nomass_iters, fa, write_out);
                 break;
             case 0:
-                fast_tile_march<4, kNm, 1, 0, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
-                                                 zone_T, flags, nomass_iters, fa, write_out);
+                fast_tile_march<4, kNm, 1, kCav, 0>(tile, w, nm, lane, wib, s_pal, nullptr, s_pos, fl, blk, 0, 1, step0, na, sd, weather,
+                                                    zone_T, flags, nomass_iters, fa, write_out);
                 break;
             default: {
-                unsigned int tot = small_tile_march<0>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, weather[step0],
-                                                       zone_T, flags);
+                unsigned int tot = small_tile_march<kCav>(tile.node_base, tile.surf_base, tile.G, lane, na, gen_base, sd, weather[step0],
+                                                          zone_T, flags);
 #pragma unroll
                 for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
                 if (lane == 0 && tot) nomass_iters[w] += tot;
@@ -1976,7 +1982,8 @@ void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, con
                        step_ptr, step_fixed, zone_T, flags, nomass_iters)
     if (variant == kStreamWide) HEAT_LAUNCH_STREAM(kStreamWide);
     else if (variant == kStreamLight) HEAT_LAUNCH_STREAM(kStreamLight);
-    else HEAT_LAUNCH_STREAM(kStreamChunks);
+    else if (variant == kStreamChunks) HEAT_LAUNCH_STREAM(kStreamChunks);
+    else HEAT_LAUNCH_STREAM(kStreamCav);
 #undef HEAT_LAUNCH_STREAM
 }
 

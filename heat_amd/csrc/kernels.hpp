@@ -20,8 +20,9 @@ constexpr int kStreamKindShift = 9;
 constexpr int kStreamKindSmall = 3;
 constexpr int kStreamNmBit = 1 << 11;
 // variant: 0 tiles of 16 nodes per lane, 1 tiles of 8 / 4 nodes per lane with one-node facings at most + small surfaces,
-// 2 tiles of 8 / 4 nodes per lane with other no-mass chunks (kernels.hip, k_surfaces_stream)
-constexpr int kStreamVariants = 3;
+// 2 tiles of 8 / 4 nodes per lane with other no-mass chunks, 3 tiles with gas cavities — double glazing and walls of
+// 8 / 4 nodes per lane (kernels.hip, k_surfaces_stream)
+constexpr int kStreamVariants = 4;
 void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
                             int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st);
