@@ -166,6 +166,16 @@ struct heat_batch {
     // workgroup lists per class: index = width group (0: <= 4 wavefronts, 1: <= 8) + 2 * mixed (small-surface tiles too)
     std::vector<FusedBlock> h_fblocks[kNumFast][4];
     DevBuf<FusedBlock> d_fblocks[kNumFast][4];
+    // teams of workgroups (clusters larger than one workgroup; layout.hpp, FusedSuper)
+    std::vector<FusedBlock> h_team_blocks[kNumFast], h_team_blocks0[kNumFast];
+    std::vector<FusedSuper> h_team_supers[kNumFast];
+    DevBuf<FusedBlock> d_team_blocks[kNumFast];
+    DevBuf<FusedSuper> d_team_supers[kNumFast];
+    DevBuf<uint32_t> d_team_zinfo;
+    DevBuf<unsigned long long> d_xbuf;  // the teams' exchange areas (allocated with the first team launch)
+    int xbuf_teams = 0;                 // teams the exchange areas are sized for
+    uint32_t team_epoch = 0;            // launches so far: names the granules of a launch (tag_base)
+    bool any_teams = false;
     DevBuf<unsigned int> d_fqueue;      // work-queue counters of the fused launches (sharded batches): one per list
     DevBuf<int32_t> d_fzones, d_fzone_eoff;
     DevBuf<uint16_t> d_fslots;
@@ -339,6 +349,9 @@ int flags_to_status(int f) {
     if (f & FLAG_NAN_NOMASS) return fail(HEAT_N_NAN_NOMASS, "NaN error in the no-mass loop (reference: surface.rs:850)");
     if (f & FLAG_NAN_ZONE) return fail(HEAT_N_NAN_ZONE, "NaN zone temperature (reference: model.rs:417)");
     if (f & FLAG_UNREACHABLE) return fail(HEAT_N_UNREACHABLE, "unreachable!() branch taken (NaN input)");
+    if (f & FLAG_EXCHANGE)
+        return fail(HEAT_E_DEVICE, "cluster-resident march: a workgroup of a team gave up waiting for another member's zone sums "
+                                   "(the state of this march call is not to be used)");
     return HEAT_OK;
 }
 
@@ -376,6 +389,11 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
             b->h_fblocks[c][g2] = b->h_fblocks0[c][g2] = p.fblocks[c][g2];
             HIP_TRY(b->d_fblocks[c][g2].upload(p.fblocks[c][g2]));
         }
+        b->h_team_blocks[c] = b->h_team_blocks0[c] = p.team_blocks[c];
+        b->h_team_supers[c] = p.team_supers[c];
+        b->any_teams = b->any_teams || !p.team_supers[c].empty();
+        HIP_TRY(b->d_team_blocks[c].upload(p.team_blocks[c]));
+        HIP_TRY(b->d_team_supers[c].upload(p.team_supers[c]));
         b->h_tiles0[c] = b->h_tiles_cur[c] = p.fast_tiles[c];
         b->n_stream_tiles[c] = b->n_stream_tiles0[c] = p.n_stream_tiles[c];
         b->n_fast_tiles[c] = (int)p.fast_tiles[c].size();
@@ -386,6 +404,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     b->h_fzones = p.fzones;
     HIP_TRY(b->d_fzones.upload(p.fzones));
     HIP_TRY(b->d_fzone_eoff.upload(p.fzone_eoff));
+    HIP_TRY(b->d_team_zinfo.upload(p.team_zinfo));
     HIP_TRY(b->d_fslots.upload(p.fslots));
     HIP_TRY(b->d_side_area.upload(p.side_area));
     HIP_TRY(b->d_side_lzone.upload(p.side_lzone));
@@ -867,6 +886,47 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
                                           b->na, b->sa, b->d_weather.p, b->d_flags.p,
                                           b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
         }
+    // Teams (clusters larger than a workgroup): n_teams x kTeamMax workgroups, ALL of them on the chip at once — a member
+    // waits for the others' zone sums, so no workgroup of the launch may have to wait for a slot a waiting one holds.
+    for (int c = 0; c < kNumFast; c++) {
+        const int n_super = (int)b->h_team_supers[c].size();
+        if (n_super == 0) continue;
+        if (n_sub > 4095) return fail(HEAT_E_INVALID_ARG, "a march call of %d sub-timesteps: the team exchange tags 4095 at most", n_sub);
+        // what the chip holds of this variant, less a margin (the hardware may admit a workgroup per compute unit fewer than
+        // the occupancy arithmetic says); other kernels in flight only delay a member's start, they end by themselves
+        const int room = n_cu * fused_blocks_per_cu(kFastM[c], 0, 0, 4, b->na.pal_stride);
+        int team_size = 2;
+        for (const FusedSuper &su : b->h_team_supers[c]) team_size = std::max(team_size, (int)su.n_members);
+        const int n_teams = std::min(n_super, std::max(0, room - room / 8) / team_size);
+        if (n_teams >= 1 && (n_super + n_teams - 1) / n_teams > 1023)
+            return fail(HEAT_E_SIZE, "%d clusters for %d teams: the exchange tags 1023 rounds per launch at most", n_super, n_teams);
+        if (n_teams < 1) return fail(HEAT_E_DEVICE, "the device holds %d workgroups of the team variant: not one team", room);
+        if (b->xbuf_teams < n_teams) {
+            HIP_TRY(b->d_xbuf.zeros((size_t)n_teams * 2 * kTeamZones * kTeamMax * 4));
+            b->xbuf_teams = n_teams;
+        }
+        b->team_epoch++;
+        if ((b->team_epoch & 1023u) == 0) {  // the 10-bit launch number wraps: no granule of the launch 1024 before may survive
+            HIP_TRY(hipMemsetAsync(b->d_xbuf.p, 0, b->d_xbuf.n * sizeof(unsigned long long), st));
+            b->team_epoch++;
+        }
+        fa.blocks = b->d_team_blocks[c].p;
+        fa.n_blocks = (int)b->h_team_blocks[c].size();
+        fa.queue = nullptr;
+        fa.supers = b->d_team_supers[c].p;
+        fa.n_super = n_super;
+        fa.team_zinfo = b->d_team_zinfo.p;
+        fa.xbuf = b->d_xbuf.p;
+        fa.tag_base = (b->team_epoch & 1023u) << 22;
+        fa.team_size = team_size;
+        static const bool trace = getenv("HEAT_AMD_TRACE") != nullptr;
+        if (trace)
+            fprintf(stderr, "heat_amd: team launch: %d teams of %d workgroups for %d clusters (class %d, %d sub-timesteps)\n",
+                    n_teams, team_size, n_super, c, n_sub);
+        b->n_fused_launches++;
+        HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], 0, 2, 4, n_teams * team_size, b->d_fast_tiles[c].p, b->n_fast_tiles[c], b->na,
+                                      b->sa, b->d_weather.p, b->d_flags.p, b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
+    }
     return HEAT_OK;
 }
 
@@ -1333,9 +1393,15 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         HIP_TRY(b->d_gen_tiles.upload(g));
         b->h_gen_tiles_cur = g;
     }
+    // (teams are never demoted: a zone shared with another rank cannot also be exchanged inside a team)
+    for (int c = 0; c < kNumFast; c++)
+        for (const FusedBlock &fb : b->h_team_blocks0[c])
+            if (owns_shared_zone(fb))
+                return fail(HEAT_E_INVALID_ARG, "zone shared between ranks belongs to a cluster marched by a team of workgroups "
+                                                "(create the batch with no_fusion = 1, or do not share that zone)");
     for (int c = 0; c < kNumFast; c++) {
         const std::vector<FastTile> &t0 = b->h_tiles0[c];
-        bool any = false;
+        bool any = !b->h_team_blocks0[c].empty();
         for (int g2 = 0; g2 < 4; g2++) any = any || !b->h_fblocks0[c][g2].empty();
         if (!any) continue;
         std::vector<FastTile> t(t0.begin(), t0.begin() + b->n_stream_tiles0[c]);
@@ -1355,6 +1421,20 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
                     }
                 }
         int n_kept_tiles = 0;
+        {   // the teams' tiles stay where they are in the order of things: behind the kept workgroups' tiles
+            std::vector<FusedBlock> tb = b->h_team_blocks0[c];
+            for (FusedBlock &fb : tb) {
+                const int first = (int)t.size();
+                t.insert(t.end(), t0.begin() + fb.first_tile, t0.begin() + fb.first_tile + fb.n_tiles);
+                fb.first_tile = first;
+                n_kept_tiles += fb.n_tiles;
+                for (int j = 0; j < fb.n_zones; j++) zone_fused[b->h_fzones[fb.first_zone + j]] = 1;
+                for (int q = 0; q < fb.n_tiles; q++) n_fused_now += t[fb.first_tile + q].G;
+            }
+            b->h_team_blocks[c] = tb;
+            HIP_TRY(b->d_team_blocks[c].upload(tb));
+            b->any_fused = b->any_fused || !tb.empty();
+        }
         for (int g2 = 0; g2 < 4; g2++) {
             for (const FusedBlock &fb : keep[g2]) {
                 n_kept_tiles += fb.n_tiles;

@@ -464,10 +464,62 @@ __device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const Fu
 // summation tree). One with more zones (buildings: rooms joined by partitions, a dozen walls each) gives every zone
 // a ROW of 16 lanes — four zones per wavefront at a time, their sums, divisions and exponentials side by side in the
 // lanes instead of one zone after the other: the serial tail of the phase is what the other wavefronts wait for.
+// TEAM: the workgroup is a member of a team (layout.hpp): a zone's sums are this member's PARTIAL sums; they are
+// published, the other members' awaited (bounded), and all of them added in member order — every member that faces the
+// zone gets the same bits.
+struct TeamCtx {
+    int team, member, round, it;
+    int *flags;
+};
+__device__ __forceinline__ unsigned long long team_granule(unsigned int data, unsigned int tag) {
+    return ((unsigned long long)tag << 32) | data;
+}
+template <int TEAM>
 __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int wib,
-                                                 int n_waves, int lane, int &bad_all) {
+                                                 int n_waves, int lane, int &bad_all, const TeamCtx &tc_) {
     __syncthreads();
     auto finish = [&](int j, double a, double b, double tc, double cz) {
+        if constexpr (TEAM) {
+            const unsigned int info = fa.team_zinfo[blk.first_zone + j];
+            const unsigned int slot = info & 0xffffu, mask = info >> 16;
+            const unsigned int tag = fa.tag_base | ((unsigned int)tc_.round << 12) | (unsigned int)(tc_.it + 1);
+            unsigned long long *area = fa.xbuf + ((((size_t)tc_.team * 2 + (tc_.it & 1)) * kTeamZones + slot) * kTeamMax) * 4;
+            {   // publish this member's partial sums: four granules, one write-through store each
+                unsigned long long *g = area + tc_.member * 4;
+                const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+                __hip_atomic_store(g + 0, team_granule((unsigned int)ab, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, team_granule((unsigned int)(ab >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 2, team_granule((unsigned int)bb, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 3, team_granule((unsigned int)(bb >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            double sa = 0.0, sb = 0.0;
+            for (int m = 0; m < kTeamMax; m++) {
+                if (!((mask >> m) & 1u)) continue;
+                double am = a, bm = b;
+                if (m != tc_.member) {
+                    const unsigned long long *g = area + m * 4;
+                    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+                    bool got = false;
+                    for (int spin = 0; spin < (1 << 21); spin++) {  // (~1 us per poll under load: seconds before giving up)
+                        g0 = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        got = (unsigned int)(g0 >> 32) == tag && (unsigned int)(g1 >> 32) == tag &&
+                              (unsigned int)(g2 >> 32) == tag && (unsigned int)(g3 >> 32) == tag;
+                        if (got) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    if (!got) atomicOr(tc_.flags, FLAG_EXCHANGE);  // (the member never came: reported, not waited for)
+                    am = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
+                    bm = __longlong_as_double((long long)((g2 & 0xffffffffull) | (g3 << 32)));
+                }
+                sa += am;
+                sb += bm;
+            }
+            a = sa;
+            b = sb;
+        }
         a += l.za0[j];
         b += l.zb0[j];
         double ft = tc;
@@ -563,7 +615,7 @@ __device__ void fused_small_wave(const FusedBlock &blk, const FusedArgs &fa, con
             if ((cf.kind_n & 3) == KIND_SPACE) l.hT[l.slots[wib * kWave + lane]] = make_double2(of.hs * area, T.a);
             if ((cb.kind_n & 3) == KIND_SPACE) l.hT[l.slots[lanes_per_side + wib * kWave + lane]] = make_double2(ob.hs * area, Tl);
         }
-        fused_zone_phase(blk, fa, l, wib, n_waves, lane, bad_all);
+        fused_zone_phase<0>(blk, fa, l, wib, n_waves, lane, bad_all, TeamCtx{0, 0, 0, 0, nullptr});
     }
     if ((int)threadIdx.x < blk.n_zones) fa.zone_T[fa.zones[blk.first_zone + threadIdx.x]] = l.zT[threadIdx.x];
     if (active) {
@@ -603,14 +655,14 @@ __device__ unsigned long long g_stamps[65536 * kStampsPerBlock];
 //   counter_index  slot of the tile in `nomass_iters` (NM)
 //   nm_on          NM variants: whether this tile holds walls with no-mass facings at all (wave-uniform; the unified
 //                  streamed kernel runs all-massive and faced tiles through one variant)
-template <int M, int NM, int PAL, int CAV, int FUSED>
+template <int M, int NM, int PAL, int CAV, int FUSED, int SMALL = 0>
 __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter_index, bool nm_on, int lane, int wib,
                                                 double *s_pal, double *s_V, double *s_pos, const FusedLds &fl, const FusedBlock &blk,
                                                 int blk_waves, int n_it, int step0, const NodeArrays &na,
                                                 const SideArrays &sd, const StepWeather *__restrict__ weather,
                                                 const double *__restrict__ zone_T, int *__restrict__ flags,
                                                 unsigned long long *__restrict__ nomass_iters, const FusedArgs &fa,
-                                                bool write_out = true) {
+                                                bool write_out = true, const TeamCtx team = TeamCtx{0, 0, 0, 0, nullptr}) {
     constexpr int kLanes = (FUSED ? FUSED : 4) * kWave;
     constexpr bool kVinLds = FUSED && M == 16;
     HEAT_STAMP(4, true);
@@ -1185,7 +1237,13 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         asm volatile("" : "+v"(sidx_next));  // (a fresh load, not the value of the pass before kept in registers)
         c_cur = sd.sc[sidx_next];
         dy_cur = sd.dyn[sidx_next];
-        fused_zone_phase(blk, fa, fl, wib, blk_waves, lane, bad_all);
+        if constexpr (SMALL == 2) {
+            TeamCtx tcx = team;
+            tcx.it = it;
+            fused_zone_phase<1>(blk, fa, fl, wib, blk_waves, lane, bad_all, tcx);
+        } else {
+            fused_zone_phase<0>(blk, fa, fl, wib, blk_waves, lane, bad_all, team);
+        }
     }
     }  // sub-timesteps
     HEAT_STAMP(2, false);
@@ -1284,14 +1342,36 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     // Streaming (FUSED = 0), persistent waves: each walks the tile list with a grid stride, so the write-back of
     // one tile (a wave cannot retire before its stores are acknowledged) overlaps the loads of the next.
     // FUSED: one pass per FusedBlock; with a work queue (sharded batches, fa.queue) the workgroup takes further ones.
-    for (int wave = wave0; FUSED ? (bi < fa.n_blocks) : (wave < n_tiles); wave += n_waves) {
+    // TEAM (SMALL == 2): the workgroup is member blockIdx.x % team_size of team blockIdx.x / team_size; the team walks the
+    // clusters (FusedSuper) team, team + n_teams, ... — every member in the same order, so that the members of a cluster
+    // are always at work on it together (layout.hpp).
+    constexpr bool kTeam = FUSED && SMALL == 2;
+    TeamCtx team{0, 0, 0, 0, flags};
+    int sb = 0, n_teams = 1;
+    if constexpr (kTeam) {
+        team.team = (int)blockIdx.x / fa.team_size;
+        team.member = (int)blockIdx.x % fa.team_size;
+        n_teams = (int)gridDim.x / fa.team_size;
+        sb = team.team;
+    }
+    for (int wave = wave0; FUSED ? (kTeam ? (sb < fa.n_super) : (bi < fa.n_blocks)) : (wave < n_tiles); wave += n_waves) {
     if constexpr (FUSED) {
+        if constexpr (kTeam) {
+            const FusedSuper su = fa.supers[sb];
+            if (team.member >= su.n_members) {  // (the whole workgroup: this cluster has fewer members than a team)
+                sb += n_teams;
+                team.round++;
+                continue;
+            }
+            bi = su.first_block + team.member;
+        }
         blk = fa.blocks[bi];
-        blk_waves = blk.n_tiles + (SMALL ? blk.n_small : 0);
+        blk_waves = blk.n_tiles + (SMALL == 1 ? blk.n_small : 0);
+        const bool looping = kTeam || fa.queue != nullptr;  // the workgroup goes on to another block after this one
         if (wib >= blk_waves) {
             // no tile for this wavefront. One FusedBlock per workgroup: done (a finished wave does not take part in
-            // s_barrier). With the queue it has to stay for the next block, and keeps step with the barriers.
-            if (fa.queue == nullptr) return;
+            // s_barrier). A workgroup that goes on to another block keeps the wavefront, in step with the barriers.
+            if (!looping) return;
             // kFusedBarriersAtInit + kFusedBarriersPerSubstep * n_sub: the same count as a working wavefront passes
             // (fused_block_init ends with one barrier, fused_zone_phase brackets the zone sums with two)
             for (int q = 0; q < kFusedBarriersAtInit; q++) __syncthreads();
@@ -1299,24 +1379,30 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
                 for (int q = 0; q < kFusedBarriersPerSubstep; q++) __syncthreads();
             goto next_block;
         }
-        if constexpr (SMALL) {
+        if constexpr (SMALL == 1) {
             if (wib >= blk.n_tiles) {
                 fused_small_wave(blk, fa, fl, kLanes, wib, blk_waves, lane, na, sd, weather, flags);
-                if (fa.queue == nullptr) return;
+                if (!looping) return;
                 goto next_block;
             }
         }
         wave = blk.first_tile + wib;
     }
-    fast_tile_march<M, NM, PAL, CAV, FUSED>(tiles[wave], wave, true, lane, wib, s_pal, s_V, s_pos_static, fl, blk, blk_waves, n_it, step0, na,
-                                            sd, weather, zone_T, flags, nomass_iters, fa, write_out);
+    fast_tile_march<M, NM, PAL, CAV, FUSED, SMALL>(tiles[wave], wave, true, lane, wib, s_pal, s_V, s_pos_static, fl, blk, blk_waves, n_it, step0, na,
+                                                   sd, weather, zone_T, flags, nomass_iters, fa, write_out, team);
 next_block:
     if constexpr (FUSED) {
-        if (fa.queue == nullptr) break;
-        __syncthreads();  // every wavefront is done with this block's LDS
-        if (threadIdx.x == 0) s_next_block = (int)(gridDim.x + atomicAdd(fa.queue, 1u));
-        __syncthreads();
-        bi = s_next_block;
+        if constexpr (kTeam) {
+            __syncthreads();  // every wavefront is done with this block's LDS
+            sb += n_teams;
+            team.round++;
+        } else {
+            if (fa.queue == nullptr) break;
+            __syncthreads();  // every wavefront is done with this block's LDS
+            if (threadIdx.x == 0) s_next_block = (int)(gridDim.x + atomicAdd(fa.queue, 1u));
+            __syncthreads();
+            bi = s_next_block;
+        }
     }
     }  // tile / block loop
 }
@@ -2016,8 +2102,9 @@ static hipError_t launch_fused_one(int grid_blocks, const FastTile *tiles, int n
     return hipSuccess;
 }
 
-// mixed: the workgroups also hold small-surface wavefronts; those run one universal variant per blocking factor
-// (no-mass facings allowed, gas cavities allowed up to 8 nodes per lane).
+// mixed = 1: the workgroups also hold small-surface wavefronts; those run one universal variant per blocking factor
+// (no-mass facings allowed, gas cavities allowed up to 8 nodes per lane). mixed = 2: teams (layout.hpp, FusedSuper):
+// grid_blocks = n_teams * kTeamMax, fa.supers / team_zinfo / xbuf / tag_base set.
 // How many workgroups of a fused variant one compute unit holds (two waves per SIMD by registers; three for the
 // plain 4-node variants), also bounded by LDS.
 int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves, int pal_stride) {
@@ -2036,6 +2123,12 @@ hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_wave
     if (cav && M == 16) return hipErrorInvalidValue;  // (the planner never asks for it)
 #define HEAT_FUSED(MM, NN, CC, FW, SM) \
     launch_fused_one<MM, NN, CC, FW, SM>(n_blocks, tiles, n_tiles, na, sa, weather, flags, nomass_iters, fa, st)
+    if (mixed == 2) {  // teams of workgroups (clusters larger than one): four wavefronts each, no cavities, no small surfaces
+        if (cav || max_waves > 4) return hipErrorInvalidValue;
+        if (M == 4) return nm ? HEAT_FUSED(4, 1, 0, 4, 2) : HEAT_FUSED(4, 0, 0, 4, 2);
+        if (M == 8) return nm ? HEAT_FUSED(8, 1, 0, 4, 2) : HEAT_FUSED(8, 0, 0, 4, 2);
+        return nm ? HEAT_FUSED(16, 1, 0, 4, 2) : HEAT_FUSED(16, 0, 0, 4, 2);
+    }
     if (mixed) {
         if (M == 4) return max_waves <= 4 ? HEAT_FUSED(4, 1, 1, 4, 1) : HEAT_FUSED(4, 1, 1, 8, 1);
         if (M == 8) return max_waves <= 4 ? HEAT_FUSED(8, 1, 1, 4, 1) : HEAT_FUSED(8, 1, 1, 8, 1);

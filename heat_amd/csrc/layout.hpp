@@ -28,7 +28,8 @@ constexpr double kMassThreshold = 1e-5;    // reference src/discretization.rs:14
 enum : int { KIND_SPACE = 0, KIND_AMBIENT = 1, KIND_OUTDOOR = 2 };
 
 // Device-side numerical flags (OR-ed).
-enum : int { FLAG_NAN_HS = 1, FLAG_NAN_NOMASS = 2, FLAG_NAN_ZONE = 4, FLAG_UNREACHABLE = 8 };
+enum : int { FLAG_NAN_HS = 1, FLAG_NAN_NOMASS = 2, FLAG_NAN_ZONE = 4, FLAG_UNREACHABLE = 8,
+              FLAG_EXCHANGE = 16 };  // a team of workgroups gave up waiting for a member's zone sums (kernels.hip)
 
 struct FastTile {
     int64_t node_base;  // in doubles, into the unified node buffers
@@ -198,6 +199,33 @@ struct FusedArgs {
     const GeneralTile *gen_tiles;        // workgroups with small surfaces
     int64_t gen_base;
     unsigned long long *small_iters;     // no-mass pass counters of the general-layout tiles ([tile][lane])
+    // teams (clusters larger than a workgroup; below)
+    const struct FusedSuper *supers;
+    const uint32_t *team_zinfo;
+    unsigned long long *xbuf;            // the teams' exchange areas
+    int32_t n_super;
+    uint32_t tag_base;                   // launch number << 22 (tag = tag_base | round << 12 | sub-timestep + 1)
+    int32_t team_size;                   // workgroups per team in this launch: the most members a cluster of the list has
+    int32_t pad3;
+};
+
+// Clusters larger than a workgroup (a building whose rooms are all joined by interior walls): a TEAM of up to
+// kTeamMax workgroups of four wavefronts marches the cluster together. Every member holds part of the walls and the
+// zones they face; a zone faced from several members is balanced from all their partial sums, which the members
+// exchange through L2 once per sub-timestep as 8-byte {32 bits of data, 32-bit tag} granules (one `sc1` store each;
+// the tag names launch, round and sub-timestep, so a granule is complete when its tag is) — no flag, no fence.
+//   team_zinfo[first_zone + j]  low 16 bits: the zone's slot in the team's exchange area (its number in the cluster);
+//                               high bits: which members face it (the only ones whose sums are awaited)
+//   exchange area of a team     [parity of the sub-timestep][kTeamZones][kTeamMax][4 granules: a lo, a hi, b lo, b hi]
+// Co-residency (a member must not wait for a workgroup that cannot start): the launch holds exactly n_teams x team_size
+// workgroups (team_size: the most members a cluster of the launch has), never more than the chip takes at once (checked on the host), and every team walks the clusters
+// team, team + n_teams, ... in lockstep. Every wait is bounded: on expiry FLAG_EXCHANGE is raised and the march goes
+// on unsynchronised — the host reports HEAT_E_DEVICE.
+constexpr int kTeamMax = 8;      // workgroups per team
+constexpr int kTeamZones = 256;  // zones per cluster marched by a team
+struct FusedSuper {
+    int32_t first_block;  // into the team list of FusedBlocks; the members' blocks are contiguous
+    int32_t n_members;    // <= kTeamMax
 };
 
 struct ZoneEntry {

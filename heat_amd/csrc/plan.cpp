@@ -288,7 +288,10 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     // fast-path wall without cavities and it fits kFusedMaxWaves tiles / kFusedMaxZones zones; its surfaces then
     // share one blocking factor (4 or 8: the 16-node variant does not fit the register file with the state that
     // lives across sub-timesteps). Surfaces that face no zone at all are clusters of one and are packed freely.
-    struct BlockPlan { int cls; bool mixed; std::vector<int32_t> zones; };  // mixed: holds small-surface tiles too
+    // mixed: holds small-surface tiles too. super >= 0: member `member` of a team (layout.hpp, FusedSuper); zinfo: per
+    // zone of the block its exchange slot | members << 16
+    struct BlockPlan { int cls; bool mixed; std::vector<int32_t> zones; int super = -1; int member = 0; std::vector<uint32_t> zinfo; };
+    int n_supers = 0;
     std::vector<BlockPlan> blocks;
     // no_fusion: 0 = fuse the clusters the cost model below expects to gain, 1 = never, 2 = every cluster that can be
     const bool fuse = opt.no_fusion != 1 && !opt.force_general && !opt.no_palette;
@@ -341,7 +344,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         struct Open { int blk = -1; int cnt[kWave + 1] = {}; int nsmall = 0; int nz = 0; int ne = 0; };
         Open open[2 * kNumFast];  // [class][mixed]
         auto new_block = [&](int cls, bool mixed) {
-            blocks.push_back(BlockPlan{cls, mixed, {}});
+            blocks.push_back(BlockPlan{cls, mixed, {}, -1, 0, {}});
             return (int)blocks.size() - 1;
         };
         auto small_tiles = [](int n_small) { return (n_small + kWave - 1) / kWave; };
@@ -416,8 +419,97 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             }
             const int nz = (int)czones[r].size();
             if (!fits || tiles_needed_packed(cnt) + small_tiles(n_small) > max_tiles(M) || nz > kFusedMaxZones ||
-                ne > kFusedMaxEntries)
-                continue;  // streamed
+                ne > kFusedMaxEntries) {
+                // Too large for one workgroup: a TEAM of up to kTeamMax workgroups of four wavefronts (layout.hpp). The
+                // cluster's walls are dealt to the members room by room (by the smaller zone they face), so that most
+                // zones are faced from one member only; a zone faced from several is balanced from their partial sums.
+                static const bool teams_off = getenv("HEAT_AMD_NO_TEAMS") != nullptr;
+                if (teams_off || opt.n_ranks > 1 || mixed || any_cav || nz > kTeamZones) continue;  // streamed
+                int Mt = opt.nodes_per_lane;
+                if (Mt == 0) {
+                    double best = 0.0;
+                    for (int m : ms_all) {
+                        bool ok = true;
+                        double c = 0.0;
+                        for (int64_t q = coff[r]; q < coff[r + 1] && ok; q++) {
+                            const int kk = (placed[csurf[q]].n + m - 1) / m;
+                            ok = kk >= (m == 8 ? 1 : 2) && kk <= kWave && (cat[csurf[q]].m_ok & m_bit(m)) != 0;
+                            c += padded_cost(placed[csurf[q]].n, m);
+                        }
+                        if (ok && (Mt == 0 || c < best)) { Mt = m; best = c; }
+                    }
+                    if (Mt == 0) continue;  // streamed
+                }
+                std::vector<int64_t> walls(csurf.begin() + coff[r], csurf.begin() + coff[r + 1]);
+                auto room_of = [&](int64_t s) {
+                    const int32_t zf = zone_of_side(s, 0), zb = zone_of_side(s, 1);
+                    return zf < 0 ? zb : (zb < 0 ? zf : std::min(zf, zb));
+                };
+                std::stable_sort(walls.begin(), walls.end(), [&](int64_t x, int64_t y) { return room_of(x) < room_of(y); });
+                struct Member { std::vector<int64_t> walls; std::vector<int32_t> zones; int cnt[kWave + 1] = {}; int ne = 0; };
+                std::vector<Member> mem(1);
+                bool ok = true;
+                int nm_t = 0;
+                for (int64_t s : walls) {
+                    const int kk = (placed[s].n + Mt - 1) / Mt;
+                    if (kk > kWave || kk < (Mt == 8 ? 1 : 2) || !(cat[s].m_ok & m_bit(Mt))) { ok = false; break; }
+                    nm_t |= cat[s].nm;
+                    for (int attempt = 0; attempt < 2; attempt++) {
+                        Member &me = mem.back();
+                        int zadd = 0;
+                        for (int side = 0; side < 2; side++) {
+                            const int32_t z = zone_of_side(s, side);
+                            if (z >= 0 && std::find(me.zones.begin(), me.zones.end(), z) == me.zones.end() &&
+                                !(side == 1 && z == zone_of_side(s, 0))) zadd++;
+                        }
+                        const int eadd = (zone_of_side(s, 0) >= 0) + (zone_of_side(s, 1) >= 0);
+                        me.cnt[kk]++;
+                        const bool fits_m = tiles_needed_packed(me.cnt) <= 4 && (int)me.zones.size() + zadd <= kFusedMaxZones &&
+                                            me.ne + eadd <= kFusedMaxEntries;
+                        if (!fits_m) {
+                            me.cnt[kk]--;
+                            if (attempt == 1 || me.walls.empty()) { ok = false; break; }
+                            mem.emplace_back();
+                            continue;
+                        }
+                        me.walls.push_back(s);
+                        me.ne += eadd;
+                        for (int side = 0; side < 2; side++) {
+                            const int32_t z = zone_of_side(s, side);
+                            if (z >= 0 && std::find(me.zones.begin(), me.zones.end(), z) == me.zones.end()) me.zones.push_back(z);
+                        }
+                        break;
+                    }
+                    if (!ok || (int)mem.size() > kTeamMax) { ok = false; break; }
+                }
+                if (!ok || mem.size() < 2) continue;  // streamed
+                if (!fuse_always && S > 8192) {
+                    // tiles, plus what the exchange costs a member per sub-timestep (it waits ~3 us of a 512-workgroup chip)
+                    constexpr double kTeamExchangeNs = 6.0;
+                    double t = 0.0, bytes = 0.0;
+                    for (const Member &me : mem) t += cluster_ns(Mt, tiles_needed_packed(me.cnt)) + kTeamExchangeNs;
+                    for (int64_t s : walls) bytes += 32.0 * placed[s].n + 152.0;
+                    if (t > 0.85 * (bytes / kStreamBytesPerNs + kZoneNs * nz)) continue;  // streamed
+                }
+                const int cls_t = fast_class(Mt, Category{0, nm_t, 0, 1, 7});
+                // exchange slot of a zone = its number in the cluster; members that face it
+                std::vector<uint32_t> zmask(nz, 0);
+                auto slot_of = [&](int32_t z) { return (int)(std::lower_bound(czones[r].begin(), czones[r].end(), z) - czones[r].begin()); };
+                for (size_t m = 0; m < mem.size(); m++)
+                    for (int32_t z : mem[m].zones) zmask[slot_of(z)] |= 1u << m;
+                for (size_t m = 0; m < mem.size(); m++) {
+                    BlockPlan bp{cls_t, false, mem[m].zones, n_supers, (int)m, {}};
+                    for (int32_t z : mem[m].zones) bp.zinfo.push_back((uint32_t)slot_of(z) | (zmask[slot_of(z)] << 16));
+                    blocks.push_back(bp);
+                    for (int64_t s : mem[m].walls) {
+                        placed[s].blk = (int)blocks.size() - 1;
+                        placed[s].cls = cls_t;
+                        placed[s].k = (placed[s].n + Mt - 1) / Mt;
+                    }
+                }
+                n_supers++;
+                continue;
+            }
             if (!fuse_always) {
                 // No glazing in a fused workgroup: a window's no-mass loop re-evaluates its gas cavity every pass
                 // (surface.rs:814) — a long serial chain the whole workgroup would wait for at every sub-timestep's
@@ -891,8 +983,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     std::vector<int16_t> side_lz(2 * S, -1);
     p.zone_block.assign(Z, -1);
     p.any_fused = false;
+    std::vector<uint32_t> fteam;
     if (!blocks.empty()) {
-        std::vector<int32_t> lz_of_zone(Z, -1);
         std::vector<int> blk_fw(blocks.size(), 4);
         std::vector<int32_t> blk_first_zone(blocks.size(), 0);
         for (size_t bi = 0; bi < blocks.size(); bi++) {
@@ -901,14 +993,18 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             blk_first_zone[bi] = (int32_t)fz.size();
             for (size_t j = 0; j < blocks[bi].zones.size(); j++) {
                 const int32_t z = blocks[bi].zones[j];
-                lz_of_zone[z] = (int32_t)j;
                 p.zone_block[z] = (int32_t)bi;
                 fz.push_back(z);
+                fteam.push_back(blocks[bi].super >= 0 ? blocks[bi].zinfo[j] : 0u);
             }
         }
+        // (a zone belongs to ONE workgroup's list, except in a team, where every member that faces it lists it: the
+        // place of zone z in workgroup bi's list is looked up there — the lists are short)
+        auto local_zone = [&](int bi, int32_t z) -> int32_t {
+            const std::vector<int32_t> &zl = blocks[bi].zones;
+            return (int32_t)(std::find(zl.begin(), zl.end(), z) - zl.begin());
+        };
         // contributions in the reference's order inside each zone (model.rs:562-585): counting sort by fused zone
-        std::vector<int32_t> fz_index(Z, -1);
-        for (size_t i = 0; i < fz.size(); i++) fz_index[fz[i]] = (int32_t)i;
         std::vector<int32_t> cnt(fz.size() + 1, 0);
         auto side_zone = [&](int64_t s, int side) -> int32_t {
             const int kind = side ? d->back_kind[s] : d->front_kind[s];
@@ -918,7 +1014,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
         for (int64_t s = 0; s < S; s++)
             for (int side = 0; side < 2; side++) {
                 const int32_t z = side_zone(s, side);
-                if (z >= 0) cnt[fz_index[z] + 1]++;
+                if (z >= 0) cnt[blk_first_zone[placed[s].blk] + local_zone(placed[s].blk, z) + 1]++;
             }
         for (size_t i = 0; i < fz.size(); i++) cnt[i + 1] += cnt[i];
         fz_eoff.assign(cnt.begin(), cnt.end());
@@ -935,17 +1031,31 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 const int wave_in_block = (m.M == 0) ? blk_n_tiles[bi] + (m.tile - blk_first_small[bi])
                                                      : (m.tile - blk_first_tile[bi]);
                 const uint32_t slot = (uint32_t)(side * kWave * blk_fw[bi] + wave_in_block * kWave + lane);
-                fent[cur[fz_index[z]]++] = (uint16_t)slot;
-                side_lz[(int64_t)side * S + dev_of[s]] = (int16_t)lz_of_zone[z];
+                const int32_t lz = local_zone(bi, z);
+                fent[cur[blk_first_zone[bi] + lz]++] = (uint16_t)slot;
+                side_lz[(int64_t)side * S + dev_of[s]] = (int16_t)lz;
             }
+        int cur_super = -1;
         for (size_t bi = 0; bi < blocks.size(); bi++) {
             if (blk_n_tiles[bi] + blk_n_small[bi] <= 0) continue;
             FusedBlock fb{std::max(blk_first_tile[bi], 0), blk_n_tiles[bi], blk_first_zone[bi],
                           (int32_t)blocks[bi].zones.size(), std::max(blk_first_small[bi], 0), blk_n_small[bi]};
-            p.fblocks[blocks[bi].cls][(blk_fw[bi] == 4 ? 0 : 1) + (blocks[bi].mixed ? 2 : 0)].push_back(fb);
+            if (blocks[bi].super >= 0) {
+                // a team's members follow each other (they were planned in a row): one FusedSuper per team
+                std::vector<FusedBlock> &tb = p.team_blocks[blocks[bi].cls];
+                if (blocks[bi].super != cur_super) {
+                    cur_super = blocks[bi].super;
+                    p.team_supers[blocks[bi].cls].push_back(FusedSuper{(int32_t)tb.size(), 0});
+                }
+                p.team_supers[blocks[bi].cls].back().n_members++;
+                tb.push_back(fb);
+            } else {
+                p.fblocks[blocks[bi].cls][(blk_fw[bi] == 4 ? 0 : 1) + (blocks[bi].mixed ? 2 : 0)].push_back(fb);
+            }
             p.any_fused = true;
         }
     }
+    p.team_zinfo = std::move(fteam);
     // zones this batch's surfaces touch (for sharded batches)
     p.touched.assign(Z, 0);
     for (int64_t z = 0; z < Z; z++) p.touched[z] = zoff[z + 1] > zoff[z] ? 1 : 0;
@@ -1208,6 +1318,61 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
                 }
                 for (int q = 0; q < fb.n_small; q++) fused_surfaces += p.gen_tiles[fb.first_small + q].G;
             }
+    // teams (layout.hpp, FusedSuper): members of four wavefronts, a zone's sides spread over the members that list it
+    PLAN_REQUIRE(p.team_zinfo.size() == p.fzones.size(), "team zone table size");
+    {
+        std::vector<int64_t> team_sides(Z, 0);
+        for (int c = 0; c < kNumFast; c++) {
+            PLAN_REQUIRE(p.team_supers[c].empty() || (kFastPAL[c] && !kFastCAV[c]), "class %d cannot march in teams", c);
+            size_t covered = 0;
+            for (const FusedSuper &su : p.team_supers[c]) {
+                PLAN_REQUIRE(su.n_members >= 2 && su.n_members <= kTeamMax && su.first_block == (int32_t)covered &&
+                             su.first_block + su.n_members <= (int32_t)p.team_blocks[c].size(), "class %d: team of %d members at %d", c, su.n_members, su.first_block);
+                covered += (size_t)su.n_members;
+                std::vector<uint32_t> mask_seen(kTeamZones, 0), mask_told(kTeamZones, 0);
+                std::vector<int32_t> slot_zone(kTeamZones, -1);
+                for (int m = 0; m < su.n_members; m++) {
+                    const FusedBlock &fb = p.team_blocks[c][su.first_block + m];
+                    PLAN_REQUIRE(fb.n_tiles >= 1 && fb.n_tiles <= 4 && fb.n_small == 0, "team member of %d + %d wavefronts", fb.n_tiles, fb.n_small);
+                    PLAN_REQUIRE(fb.first_tile >= p.n_stream_tiles[c] && fb.first_tile + fb.n_tiles <= (int)p.fast_tiles[c].size(), "team member: tile range");
+                    PLAN_REQUIRE(fb.n_zones >= 0 && fb.n_zones <= kFusedMaxZones && fb.first_zone >= 0 &&
+                                 fb.first_zone + fb.n_zones <= (int)p.fzones.size(), "team member: zone range");
+                    const int e0 = p.fzone_eoff[fb.first_zone], e1 = p.fzone_eoff[fb.first_zone + fb.n_zones];
+                    PLAN_REQUIRE(e1 - e0 <= kFusedMaxEntries && e1 <= (int)p.fslots.size(), "team member: %d zone-facing sides", e1 - e0);
+                    for (int e = e0; e < e1; e++) PLAN_REQUIRE(p.fslots[e] < 2 * kWave * 4, "slot %d outside the workgroup", (int)p.fslots[e]);
+                    for (int j = 0; j < fb.n_zones; j++) {
+                        const int32_t z = p.fzones[fb.first_zone + j];
+                        const uint32_t info = p.team_zinfo[fb.first_zone + j], slot = info & 0xffffu;
+                        PLAN_REQUIRE(z >= 0 && z < Z && p.zone_block[z] >= 0 && slot < (uint32_t)kTeamZones, "team zone %d", z);
+                        PLAN_REQUIRE(slot_zone[slot] < 0 || slot_zone[slot] == z, "exchange slot %u names two zones", slot);
+                        PLAN_REQUIRE(((info >> 16) >> m) & 1u, "zone %d: member %d lists it but is not among its members", z, m);
+                        slot_zone[slot] = z;
+                        mask_seen[slot] |= 1u << m;
+                        mask_told[slot] = info >> 16;
+                        zone_seen[z] = 1;
+                        team_sides[z] += p.fzone_eoff[fb.first_zone + j + 1] - p.fzone_eoff[fb.first_zone + j];
+                    }
+                    for (int q = 0; q < fb.n_tiles; q++) {
+                        const FastTile &ft = p.fast_tiles[c][fb.first_tile + q];
+                        fused_surfaces += ft.G;
+                        for (int g = 0; g < ft.G; g++)
+                            for (int side = 0; side < 2; side++) {
+                                const int64_t rec = (int64_t)side * S + ft.surf_base + g;
+                                const int lz = p.side_lzone[rec];
+                                PLAN_REQUIRE(((p.side[rec].kind_n & 3) == KIND_SPACE) == (lz >= 0) && lz < fb.n_zones, "side %lld: local zone %d", (long long)rec, lz);
+                                if (lz >= 0) PLAN_REQUIRE(p.fzones[fb.first_zone + lz] == p.side[rec].zone, "side %lld: local zone maps to another zone", (long long)rec);
+                            }
+                    }
+                }
+                // every member awaited for a zone really publishes for it, and nobody else does
+                for (int q = 0; q < kTeamZones; q++) PLAN_REQUIRE(mask_seen[q] == mask_told[q], "exchange slot %d: members %x listed, %x awaited", q, mask_seen[q], mask_told[q]);
+            }
+            PLAN_REQUIRE(covered == p.team_blocks[c].size(), "class %d: team members outside any team", c);
+        }
+        // a zone marched by a team has all its sides inside the team
+        for (int64_t z = 0; z < Z; z++)
+            if (team_sides[z] > 0) PLAN_REQUIRE(team_sides[z] == p.zone_off[z + 1] - p.zone_off[z], "zone %lld: %lld sides in its team, %lld in the model", (long long)z, (long long)team_sides[z], (long long)(p.zone_off[z + 1] - p.zone_off[z]));
+    }
     for (int64_t z = 0; z < Z; z++) PLAN_REQUIRE((p.zone_block[z] >= 0) == (zone_seen[z] != 0), "zone %lld: block table and workgroup lists disagree", (long long)z);
     PLAN_REQUIRE(fused_surfaces == p.n_fused_surfaces, "%lld surfaces in workgroups, %lld counted", (long long)fused_surfaces, (long long)p.n_fused_surfaces);
     if (!p.cavref.empty()) {
@@ -1381,6 +1546,7 @@ int heat_plan_check(const heat_batch_desc *desc, const heat_batch_options *opt_i
         for (int c = 0; c < heat::kNumFast; c++) {
             n_fast_tiles += (int64_t)p.fast_tiles[c].size();
             for (int g2 = 0; g2 < 4; g2++) n_blocks += (int64_t)p.fblocks[c][g2].size();
+            n_blocks += (int64_t)p.team_blocks[c].size();
         }
         summary[0] = p.class_counts[0];
         summary[1] = p.class_counts[1];

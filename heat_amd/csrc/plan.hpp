@@ -46,6 +46,11 @@ struct Plan {
 
     // cluster-resident march: workgroup lists per class, index = width group (0: <= 4 wavefronts, 1: <= 8) + 2 * mixed
     std::vector<FusedBlock> fblocks[kNumFast][4];
+    // teams of workgroups (clusters larger than one workgroup; layout.hpp, FusedSuper): the member blocks per class, the
+    // clusters as runs of them, and per fused zone (fzones index) its exchange slot | members << 16
+    std::vector<FusedBlock> team_blocks[kNumFast];
+    std::vector<FusedSuper> team_supers[kNumFast];
+    std::vector<uint32_t> team_zinfo;
     std::vector<int32_t> fzones, fzone_eoff;
     std::vector<uint16_t> fslots;
     std::vector<double> side_area;    // [2 * S]

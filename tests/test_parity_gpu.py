@@ -368,13 +368,16 @@ def test_shards_of_the_cluster_partition_march_without_any_exchange(oracle, n_ra
 
 
 @pytest.mark.parametrize("rooms,n,kw", [(8, 20, {}), (8, 20, dict(no_fusion=True)), (8, 32, {}), (6, 9, {}),
-                                        (40, 20, {}), (16, 12, dict(fuse_always=True))])
+                                        (40, 20, {}), (40, 32, {}), (24, 13, dict(fuse_always=True)), (100, 16, {}),
+                                        (16, 12, dict(fuse_always=True))])
 def test_buildings_of_small_rooms_joined_by_partitions(oracle, rooms, n, kw):
     """Buildings as models have them (src/model.rs:556-590: a partition is in the balance of both rooms it separates):
     rooms of a dozen walls, two of them interior partitions to the next room. A building is one cluster of `rooms`
     zones: cluster-resident, its workgroup balances the zones side by side in rows of 16 lanes (more zones than
-    wavefronts); streamed — by choice, or because 40 rooms do not fit a workgroup — k_zones gives every zone a row of
-    16 lanes instead of a wavefront (few walls per zone)."""
+    wavefronts); 24 or 40 rooms do not fit a workgroup and are marched by a TEAM of workgroups that exchange the
+    partial sums of the zones they share once per sub-timestep (layout.hpp, FusedSuper); streamed — by choice, or
+    because 100 rooms do not fit a team either — k_zones gives every zone a row of 16 lanes instead of a wavefront
+    (few walls per zone)."""
     per = rooms * 12
     md, st = mdl.partitioned_buildings(5 * per, n, rooms=rooms, dt=45.0, seed=rooms + n)
     Z = md["n_zones"]
@@ -386,7 +389,7 @@ def test_buildings_of_small_rooms_joined_by_partitions(oracle, rooms, n, kw):
     assert iters == gpu_iters
     assert_state_close(md, ref, got)
     with HeatBatch(md, **kw) as b:
-        fits = rooms <= 16 and "no_fusion" not in kw
+        fits = rooms <= 40 and "no_fusion" not in kw
         assert (b.n_fused_surfaces == md["n_surfaces"]) == fits, (b.n_fused_surfaces, b.class_counts())
 
 
@@ -716,11 +719,11 @@ def test_cluster_resident_march_matches_the_oracle_and_the_streamed_march(oracle
     registers, zone balance in LDS); the others are streamed beside them. Same results as the oracle (1e-9) and as
     the all-streamed march (no_fusion), also when the march is cut into several calls."""
     md, st = mdl.clustered_massive(1500, Z=60, dt=45.0, seed=11 + npl)
-    # the first sixteen zones are chained by some of their walls into one cluster of ~400 walls: too large for a
-    # workgroup, it is streamed beside the others
-    chain = (md["back_zone"] < 16) & (np.arange(1500) % 3 == 0)
+    # the first forty zones are chained by some of their walls into one cluster of ~1000 walls: too large for a
+    # workgroup and for a team of eight, it is streamed beside the others
+    chain = (md["back_zone"] < 40) & (np.arange(1500) % 3 == 0)
     md["front_kind"] = np.where(chain, mdl.SPACE, md["front_kind"]).astype(np.int32)
-    md["front_zone"] = np.where(chain, (md["back_zone"] + 1) % 16, md["front_zone"]).astype(np.int32)
+    md["front_zone"] = np.where(chain, (md["back_zone"] + 1) % 40, md["front_zone"]).astype(np.int32)
     w = mdl.weather_series(23, 45.0, wind_speed=3.5, wind_deg=120.0)
     a0 = np.linspace(0., 60., 60)
     b0 = np.linspace(0., 2., 60)
