@@ -446,10 +446,16 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                     return zf < 0 ? zb : (zb < 0 ? zf : std::min(zf, zb));
                 };
                 std::stable_sort(walls.begin(), walls.end(), [&](int64_t x, int64_t y) { return room_of(x) < room_of(y); });
-                struct Member { std::vector<int64_t> walls; std::vector<int32_t> zones; int cnt[kWave + 1] = {}; int ne = 0; };
+                struct Member { std::vector<int64_t> walls; std::vector<int32_t> zones; int cnt[kWave + 1] = {}; int ne = 0; int lanes = 0; };
                 std::vector<Member> mem(1);
                 bool ok = true;
                 int nm_t = 0;
+                // even shares: as few members as the lanes need, each filled to the same level (a member of one tile
+                // beside two of four holds a workgroup slot for a quarter of the work)
+                int64_t all_lanes = 0;
+                for (int64_t s : walls) all_lanes += (placed[s].n + Mt - 1) / Mt;
+                const int want_members = (int)std::max<int64_t>(2, (all_lanes + 4 * kWave - 1) / (4 * kWave));
+                const int lane_target = (int)std::min<int64_t>(4 * kWave, (all_lanes + want_members - 1) / want_members + kWave / 4);
                 for (int64_t s : walls) {
                     const int kk = (placed[s].n + Mt - 1) / Mt;
                     if (kk > kWave || kk < (Mt == 8 ? 1 : 2) || !(cat[s].m_ok & m_bit(Mt))) { ok = false; break; }
@@ -465,7 +471,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                         const int eadd = (zone_of_side(s, 0) >= 0) + (zone_of_side(s, 1) >= 0);
                         me.cnt[kk]++;
                         const bool fits_m = tiles_needed_packed(me.cnt) <= 4 && (int)me.zones.size() + zadd <= kFusedMaxZones &&
-                                            me.ne + eadd <= kFusedMaxEntries;
+                                            me.ne + eadd <= kFusedMaxEntries &&
+                                            (me.lanes + kk <= lane_target || (int)mem.size() >= want_members);
                         if (!fits_m) {
                             me.cnt[kk]--;
                             if (attempt == 1 || me.walls.empty()) { ok = false; break; }
@@ -474,6 +481,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                         }
                         me.walls.push_back(s);
                         me.ne += eadd;
+                        me.lanes += kk;
                         for (int side = 0; side < 2; side++) {
                             const int32_t z = zone_of_side(s, side);
                             if (z >= 0 && std::find(me.zones.begin(), me.zones.end(), z) == me.zones.end()) me.zones.push_back(z);
