@@ -66,7 +66,7 @@ VALU_CYCLES_F64, VALU_CYCLES_OTHER = 4.0, 2.0
 # ~ 4 (5 + 2) + 12 = 40 flops per node-update of the RK4 stencil (boundary work is O(1) per surface)
 ALGORITHMIC_FLOPS_PER_NODE_UPDATE = 40.0
 
-CONFIGS = ("headline", "2", "3", "5", "partitions")
+CONFIGS = ("headline", "2", "3", "5", "partitions", "buildings40", "5x10")
 KERNEL_SOURCES = ("heat_amd/csrc/kernels.hip", "heat_amd/csrc/device_math.hpp", "heat_amd/csrc/layout.hpp")
 
 
@@ -121,6 +121,16 @@ def build_config(name, args, dt, seed):
         return md, state, ("buildings with interior partitions: %d all-massive walls x %d nodes in buildings of 8 rooms "
                            "x 12 walls, 2 walls of every room are partitions to neighbouring rooms (front and back both "
                            "Space, different zones): clusters of 8 zones, dt = %g s" % (S, args.nodes, dt))
+    if name == "buildings40":
+        md, state = mdl.partitioned_buildings(S, args.nodes, rooms=40, dt=dt, seed=seed)
+        return md, state, ("buildings of 40 rooms: %d all-massive walls x %d nodes, 12 walls per room, 2 of them partitions to "
+                           "neighbouring rooms: clusters of 40 zones and 480 walls — larger than a workgroup, marched by teams "
+                           "of workgroups (layout.hpp, FusedSuper), dt = %g s" % (int(md["n_surfaces"]), args.nodes, dt))
+    if name == "5x10":
+        S5 = 2 * S
+        md, state = mdl.glazing_cavity(S5, Z=max(1, S5 // 100), dt=dt)
+        return md, state, ("BASELINE config 5 at ten times its size: %d double glazings + %d Trombe-like walls, dt = %g s"
+                           % (S5 // 2, S5 // 2, dt))
     raise SystemExit("unknown --config %r" % name)
 
 
@@ -357,7 +367,7 @@ def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
                                            "(iterate_surfaces: RK4 stencil + boundary updates, one sub-timestep per launch)")
             # the same bytes over the wall-clock time of a step of the timed region (graph replay, launches and all)
             res["roofline"]["frac_wall_clock_step"] = ab / (elapsed / K) / 1e9 / HBM_PEAK_GBS
-            if config == "5":
+            if config in ("5", "5x10"):
                 res["roofline"]["bound_note"] = (
                     "config 5 moves 0.1 GB per sub-timestep: HBM is not what bounds it. Its time is the no-mass "
                     "fixed-point loop of the glazing (Cavity::u_value + Nusselt correlations re-evaluated every pass, "
@@ -573,7 +583,7 @@ def main():
             result.update(single_gpu_leg(args.config, args, K, W, P, seed, local_rank, True, 12.0))
             if args.config == "headline" and not args.no_configs:
                 result["configs"] = {}
-                for name in ("3", "5", "2", "partitions"):
+                for name in ("3", "5", "2", "partitions", "buildings40", "5x10"):
                     t0 = time.perf_counter()
                     try:
                         leg = single_gpu_leg(name, args, args.config_steps, 20, P, seed, local_rank, False, 4.0)

@@ -5,23 +5,31 @@ import csv, glob, hashlib, json, os, sys
 tag, d, kname, config, S, N, mode, sub = sys.argv[1:9]
 S, N, sub = int(S), int(N), int(sub)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-acc = {}
+# (a sub-timestep may be several kernels — the streamed parts of k_surfaces_stream<V> —: per counter the means of every
+# matching kernel are ADDED; every such kernel runs once per sub-timestep)
+per_kernel = {}
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if kname not in r["Kernel_Name"]:
             continue
-        c = acc.setdefault(r["Counter_Name"], [0.0, 0, 0.0])
+        kn = r["Kernel_Name"].split("(")[0]
+        c = per_kernel.setdefault(kn, {}).setdefault(r["Counter_Name"], [0.0, 0, 0.0])
         c[0] += float(r["Counter_Value"]); c[1] += 1
         c[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-m = {c: v[0] / v[1] for c, v in acc.items()}
+acc = {}
+for kn, cs in per_kernel.items():
+    for cn, v in cs.items():
+        a = acc.setdefault(cn, [0.0, 0, 0.0])
+        a[0] += v[0] / v[1]; a[1] = max(a[1], v[1]); a[2] += v[2] / v[1]
+m = {c: v[0] for c, v in acc.items()}
 # the kernel sources these counters were measured on: bench.py prints "counters_stale": true (and drops every figure
 # derived from this file) when its own hash of the same files differs
 sys.path.insert(0, ROOT)
 import bench
 j = {"kernel_sources_sha256": bench.kernel_source_hash(), "kernel_sources": list(bench.KERNEL_SOURCES),
      "workload": {"config": config, "surfaces": S, "nodes_total": N, "mode": mode, "substeps_per_launch": sub},
-     "kernel": kname, "dispatches_sampled": {c: v[1] for c, v in acc.items()},
-     "mean_duration_us_under_pmc": {c: v[2] / v[1] for c, v in acc.items()},
+     "kernel": kname, "kernels_matched": sorted(per_kernel), "dispatches_sampled": {c: v[1] for c, v in acc.items()},
+     "mean_duration_us_under_pmc": {c: v[2] for c, v in acc.items()},
      "counters_per_launch": m}
 f64 = [m.get("SQ_INSTS_VALU_%s_F64" % k) for k in ("ADD", "MUL", "FMA", "TRANS")]
 if all(v is not None for v in f64):

@@ -24,8 +24,9 @@ stats cfg3 --config 3 --steps 100 --warmup 20
 stats cfg5 --config 5 --steps 100 --warmup 20
 stats cfg2 --config 2 --steps 200 --warmup 20
 stats partitions --config partitions --steps 100 --warmup 20
+stats buildings40 --config buildings40 --steps 100 --warmup 20
 fi
-[ "$part" = stats ] && { echo "bundle $tag stats done"; exit 0; }
+[ "$part" = stats ] && { mkdir -p $out/profiles && cp $R/profiles/${tag}_* $out/profiles/; echo "bundle $tag stats done"; exit 0; }
 # counters: tools/run_config.py CONFIG P REPS MODE
 $R/tools/pmc_passes.sh $out/pmc_headline_fused -- python3 $R/tools/run_config.py headline 20 2 plan
 python3 $R/tools/make_counters.py ${tag}_headline_fused $out/pmc_headline_fused "k_surfaces_fast<16, 0, 1, 0, 4" headline 1000000 32000000 fused 20
@@ -34,7 +35,9 @@ python3 $R/tools/make_counters.py ${tag}_headline_streamed $out/pmc_headline_str
 $R/tools/pmc_passes.sh $out/pmc_cfg3 -- python3 $R/tools/run_config.py 3 10 1 stream
 python3 $R/tools/make_counters.py ${tag}_cfg3_streamed $out/pmc_cfg3 "k_surfaces_stream" 3 1000000 32609258 streamed 1
 $R/tools/pmc_passes.sh $out/pmc_cfg5 -- python3 $R/tools/run_config.py 5 10 1 stream
-python3 $R/tools/make_counters.py ${tag}_cfg5_streamed $out/pmc_cfg5 "k_surfaces_" 5 200000 2096503 streamed 1
+python3 $R/tools/make_counters.py ${tag}_cfg5_streamed $out/pmc_cfg5 "k_surfaces_stream" 5 200000 2096503 streamed 1
+$R/tools/pmc_passes.sh $out/pmc_b40 -- python3 $R/tools/run_config.py buildings40 20 2 plan
+python3 $R/tools/make_counters.py ${tag}_buildings40_fused $out/pmc_b40 "k_surfaces_fast<16, 0, 1, 0, 4, 2" buildings40 999840 31994880 fused 20
 $R/tools/pmc_passes.sh $out/pmc_partitions -- python3 $R/tools/run_config.py partitions 20 2 plan
 python3 $R/tools/make_counters.py ${tag}_partitions_fused $out/pmc_partitions "k_surfaces_fast<16, 0, 1, 0, 4" partitions 999936 31997952 fused 20
 $R/tools/pmc_passes.sh $out/pmc_cfg2 -- python3 $R/tools/run_config.py 2 20 5 plan
@@ -43,4 +46,5 @@ python3 $R/tools/make_counters.py ${tag}_cfg2_fused $out/pmc_cfg2 "k_surfaces_fa
 python3 $R/tools/fused_phases.py headline 20 > $R/profiles/${tag}_fused_phases.txt
 python3 $R/tools/fused_phases.py headline 5 >> $R/profiles/${tag}_fused_phases.txt
 python3 $R/tools/fused_phases.py partitions 20 >> $R/profiles/${tag}_fused_phases.txt
+mkdir -p $out/profiles && cp $R/profiles/${tag}_* $out/profiles/   # (gpurun brings back gpurun_out/ only)
 echo "bundle $tag done"
