@@ -882,7 +882,9 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
                 fprintf(stderr, "heat_amd: fused launch%s: %d workgroups for %d blocks (class %d, list %d, %d sub-timesteps)\n",
                         fa.queue ? " on the work queue" : "", grid, nb, c, g2, n_sub);
             b->n_fused_launches++;
-            HIP_TRY(launch_surfaces_fused(kFastM[c], kFastNM[c], kFastCAV[c], g2 >> 1, (g2 & 1) ? 8 : 4, grid, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
+            // (a class whose walls hold no-mass chunks other than facings marches with the variant that carries the chunk loop)
+            const int nm_variant = kFastNM[c] ? ((b->class_has_chunks[c] && !(g2 >> 1) && !kFastCAV[c] && kFastM[c] <= 8) ? 2 : 1) : 0;
+            HIP_TRY(launch_surfaces_fused(kFastM[c], nm_variant, kFastCAV[c], g2 >> 1, (g2 & 1) ? 8 : 4, grid, b->d_fast_tiles[c].p, b->n_fast_tiles[c],
                                           b->na, b->sa, b->d_weather.p, b->d_flags.p,
                                           b->d_nomass_iters.p + b->nm_count_base[c], fa, st));
         }

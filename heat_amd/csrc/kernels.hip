@@ -676,7 +676,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     // chunk loop's registers would cost every fused NM variant, used or not)
     // NM = 2 compiles that chunk loop in; NM = 1 knows one-node facings only (its face terms live in ten registers
     // fewer: what puts the 8-node streamed body under the 168 registers of three wavefronts per SIMD)
-    constexpr bool kChunks = NM == 2 && PAL && !FUSED;
+    constexpr bool kChunks = NM == 2 && PAL;
     const bool chunky = kChunks && (tile.k & kTileChunkyBit) != 0;
     const int k = tile.k & 0xff;                              // lanes per surface; mixed: lanes of the tile
     const bool full = (tile.k & 0x100) != 0;
@@ -2133,6 +2133,10 @@ hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_wave
         if (M == 4) return max_waves <= 4 ? HEAT_FUSED(4, 1, 1, 4, 1) : HEAT_FUSED(4, 1, 1, 8, 1);
         if (M == 8) return max_waves <= 4 ? HEAT_FUSED(8, 1, 1, 4, 1) : HEAT_FUSED(8, 1, 1, 8, 1);
         return max_waves <= 4 ? HEAT_FUSED(16, 1, 0, 4, 1) : HEAT_FUSED(16, 1, 0, 8, 1);
+    }
+    if (nm == 2 && !cav && M <= 8) {  // walls with no-mass chunks other than facings (8 / 4 nodes per lane: the registers)
+        if (M == 4) return max_waves <= 4 ? HEAT_FUSED(4, 2, 0, 4, 0) : HEAT_FUSED(4, 2, 0, 8, 0);
+        return max_waves <= 4 ? HEAT_FUSED(8, 2, 0, 4, 0) : HEAT_FUSED(8, 2, 0, 8, 0);
     }
 #define HEAT_FUSED_NW(MM, CC)                                                    \
     (max_waves <= 4 ? (nm ? HEAT_FUSED(MM, 1, CC, 4, 0) : HEAT_FUSED(MM, 0, CC, 4, 0)) \

@@ -299,8 +299,9 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     const std::vector<Placed> placed_streamed = placed;  // the plan without any cluster-resident march
     if (fuse && S > 0) {
         auto is_small = [&](int64_t s) { return cat[s].kind == kSmall || cat[s].kind == kSmallCav; };
-        // (walls with no-mass chunks other than one-node facings are left to the streamed kernels)
-        auto fusable = [&](int64_t s) { return (cat[s].kind == 0 && cat[s].pal && !cat[s].chunky) || is_small(s); };
+        // (walls with no-mass chunks other than one-node facings: with 8 or 4 nodes per lane, not beside small surfaces or
+        // gas cavities — the variants that carry the chunk loop, kernels.hip)
+        auto fusable = [&](int64_t s) { return (cat[s].kind == 0 && cat[s].pal) || is_small(s); };
         auto zone_of_side = [&](int64_t s, int side) -> int32_t {
             const int kind = side ? d->back_kind[s] : d->front_kind[s];
             return kind == HEAT_BOUNDARY_SPACE ? (side ? d->back_zone[s] : d->front_zone[s]) : -1;
@@ -376,19 +377,23 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             // Small all-no-mass surfaces (glazing, thin walls) of the cluster get wavefronts of their own in the
             // workgroup (one lane per surface); such a "mixed" workgroup runs the universal kernel variant of its
             // blocking factor: no-mass facings allowed, gas cavities allowed (up to 8 nodes per lane).
-            bool any_cav = false;
+            bool any_cav = false, any_chunky = false;
             int n_small = 0;
             for (int64_t q = coff[r]; q < coff[r + 1]; q++) {
                 if (is_small(csurf[q])) n_small++;
-                else any_cav = any_cav || cat[csurf[q]].ncav > 0;
+                else {
+                    any_cav = any_cav || cat[csurf[q]].ncav > 0;
+                    any_chunky = any_chunky || cat[csurf[q]].chunky != 0;
+                }
             }
             const bool mixed = n_small > 0;
             int M = opt.nodes_per_lane;
-            if (M == 16 && any_cav) continue;  // streamed
+            if (M == 16 && (any_cav || any_chunky)) continue;  // streamed
+            if (any_chunky && (mixed || any_cav)) continue;     // streamed
             if (M == 0) {
                 double best_cost = 0.0;
                 for (int m : ms_all) {  // cheapest tiles win; on a tie the larger lanes
-                    if (m == 16 && any_cav) continue;
+                    if (m == 16 && (any_cav || any_chunky)) continue;
                     int c_k[kWave + 1] = {};
                     bool ok = true;
                     for (int64_t q = coff[r]; q < coff[r + 1] && ok; q++) {
@@ -424,7 +429,7 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 // cluster's walls are dealt to the members room by room (by the smaller zone they face), so that most
                 // zones are faced from one member only; a zone faced from several is balanced from their partial sums.
                 static const bool teams_off = getenv("HEAT_AMD_NO_TEAMS") != nullptr;
-                if (teams_off || opt.n_ranks > 1 || mixed || any_cav || nz > kTeamZones) continue;  // streamed
+                if (teams_off || opt.n_ranks > 1 || mixed || any_cav || any_chunky || nz > kTeamZones) continue;  // streamed
                 int Mt = opt.nodes_per_lane;
                 if (Mt == 0) {
                     double best = 0.0;
@@ -578,12 +583,12 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
             if (M == 0) {
                 M = 4;
                 for (int m : {8, 16})
-                    if (!(m == 16 && cav) && (cat[s].m_ok & m_bit(m)) && (pl.n + m - 1) / m >= ((m == 8 && !cav) ? 1 : 2) &&
+                    if (!(m == 16 && (cav || cat[s].chunky)) && (cat[s].m_ok & m_bit(m)) && (pl.n + m - 1) / m >= ((m == 8 && !cav) ? 1 : 2) &&
                         fused_cost(pl.n, m) <= fused_cost(pl.n, M)) M = m;
             }
             int k = (pl.n + M - 1) / M;
             const bool gains = tile_ns(M) * k / kWave < 0.85 * (32.0 * pl.n + 152.0) / kStreamBytesPerNs;
-            if (k > kWave || k < ((M == 8 && !cav) ? 1 : 2) || (M == 16 && cav) || !(cat[s].m_ok & m_bit(M)) ||
+            if (k > kWave || k < ((M == 8 && !cav) ? 1 : 2) || (M == 16 && (cav || cat[s].chunky)) || (cav && cat[s].chunky) || !(cat[s].m_ok & m_bit(M)) ||
                 (!fuse_always && S > 8192 && !gains)) { lone_ok[s] = 0; continue; }
             pl.cls = fast_class(M, Category{0, cat[s].nm, cav ? 1 : 0, 1, 7});
             pl.k = k;

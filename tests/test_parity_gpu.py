@@ -200,6 +200,25 @@ def test_nomass_chunks_inside_the_wall_and_of_two_nodes_on_the_fast_path(oracle,
         assert counts[4] < S                            # (a forced blocking factor may cut a two-node chunk in two)
     assert iters == gpu_iters and iters > 0
     assert_state_close(md, ref, got)
+    if npl in (0, 8):
+        # ... and in the cluster-resident march (the two zones are one cluster of every wall; 8 or 4 nodes per lane carry
+        # the chunk loop there): pass counts and results as the oracle's
+        # (half the walls: all of them are more wavefronts than a workgroup holds)
+        half = mdl.subset(md, np.sort(np.concatenate([np.arange(0, S, 4), np.arange(1, S, 4)])))
+        a0h, b0h = np.array([40., 0.]), np.array([1., 0.5])
+        ref_h = st.copy()
+        rc, iters_h = oracle.OracleModel(half).march(ref_h, w, a0h, b0h)
+        assert rc == 0 and iters_h > 0
+        fused = st.copy()
+        with HeatBatch(half, nodes_per_lane=npl, fuse_always=True) as b:
+            assert b.n_fused_surfaces == half["n_surfaces"], (b.n_fused_surfaces, b.class_counts())
+            b.upload_state(fused)
+            b.march(fused, w[:11], a0h, b0h)
+            b.march(fused, w[11:], a0h, b0h)
+            assert b.n_fused_launches >= 2 and b.nomass_iterations() == iters_h
+        for idx in (mdl.node_slots(half), half["hs_front_slot"], half["hs_back_slot"], half["flow_front_slot"],
+                    half["flow_back_slot"], half["zone_slot"]):
+            assert np.allclose(fused[idx], ref_h[idx], rtol=RTOL, atol=ATOL)
 
 
 def test_reference_unit_test_walls_through_the_abi(oracle):
