@@ -18,8 +18,9 @@ every sub-timestep through HBM instead, and a second, shorter leg always measure
         --master-port P bench.py --gpus N --steps K --warmup W
 
 With --config headline (the default) and one GPU the run goes on, after the headline, through the other BASELINE.json
-configs as short legs of their own — config 3 (1 M ragged mixed walls), config 5 (glazing + cavities), config 2
-(10 000 identical walls) and `partitions` (buildings of rooms joined by interior walls) — and attaches each as
+configs as short legs of their own — config 3 (1 M ragged mixed walls), config 5 (glazing + cavities; `5x10`: 1 M + 1 M
+of them), config 2 (10 000 identical walls), `partitions` (buildings of 8 rooms joined by interior walls) and
+`buildings40` (of 40 rooms: clusters larger than a workgroup, marched by teams of workgroups) — and attaches each as
 `"configs": {"3": {value, ms_per_step, roofline{...}, cpu_baseline{...}}, ...}` to the SAME JSON line
 (--no-configs skips them; `--config 3` etc. runs one of them as the main leg).
 

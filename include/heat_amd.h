@@ -266,11 +266,14 @@ int heat_batch_comm_destroy(heat_batch *b);
  * Cluster-resident march (on by default). ThermalModel::march runs its dt_subdivisions sub-timesteps back to back
  * and nothing outside reads the state in between (model.rs:369-424), and surfaces exchange heat only through the
  * zones they face (model.rs:556-590). So the batch is cut into zone-connected clusters; a cluster whose surfaces
- * are all palette-form fast-path walls (gas cavities between massive nodes allowed with 4 or 8 nodes per lane) or small
- * all-no-mass surfaces, and for which the planner's cost model expects a gain, is marched for ALL n_sub sub-timesteps
- * of a heat_batch_march[_resident] call resident on the chip: node temperatures stay in registers, the zone balance is
- * summed on the chip, and only the final temperatures, coefficients and flows are written. Everything else is streamed
- * one sub-timestep per launch. The zone sums (here and in the streamed k_zones) are lane-strided partial sums followed
+ * are all palette-form fast-path walls (gas cavities between massive nodes and no-mass chunks of one or two nodes
+ * allowed with 4 or 8 nodes per lane) or small all-no-mass surfaces, and for which the planner's cost model expects a
+ * gain, is marched for ALL n_sub sub-timesteps of a heat_batch_march[_resident] call resident on the chip: node
+ * temperatures stay in registers, the zone balance is summed on the chip, and only the final temperatures,
+ * coefficients and flows are written. A cluster of up to eight wavefronts is one workgroup's; a larger one (a building
+ * whose rooms are all joined by interior walls: up to 32 wavefronts, 256 zones) is marched by a TEAM of up to eight
+ * workgroups that exchange the partial sums of the zones they share through L2 once per sub-timestep (a march that
+ * could not complete that exchange returns HEAT_E_DEVICE). Everything else is streamed one sub-timestep per launch. The zone sums (here and in the streamed k_zones) are lane-strided partial sums followed
  * by a fixed reduction tree: deterministic run to run, but NOT the sequential surface order of model.rs:562-585 — the
  * results differ from a sequential sum by rounding (~1e-16 relative; everything is tested at 1e-9 against the oracle).
  * March calls of fewer than three sub-timesteps are streamed as well (the fused launch only pays off from three on).
