@@ -896,7 +896,8 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
         if (n_sub > 4095) return fail(HEAT_E_INVALID_ARG, "a march call of %d sub-timesteps: the team exchange tags 4095 at most", n_sub);
         // what the chip holds of this variant, less a margin (the hardware may admit a workgroup per compute unit fewer than
         // the occupancy arithmetic says); other kernels in flight only delay a member's start, they end by themselves
-        const int room = n_cu * fused_blocks_per_cu(kFastM[c], 0, 0, 4, b->na.pal_stride);
+        // (at most two per compute unit whatever the query says: the variants hold 171-256 registers)
+        const int room = n_cu * std::min(2, fused_team_blocks_per_cu(kFastM[c], kFastNM[c], b->na.pal_stride));
         int team_size = 2;
         for (const FusedSuper &su : b->h_team_supers[c]) team_size = std::max(team_size, (int)su.n_members);
         const int n_teams = std::min(n_super, std::max(0, room - room / 8) / team_size);

@@ -2114,6 +2114,23 @@ int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves, int pal_stride
     return std::min(by_regs, by_lds);
 }
 
+// Workgroups of a TEAM variant one compute unit holds at once, as the runtime's occupancy arithmetic has it for the very
+// kernel that will be launched with its dynamic LDS (the co-residency bound of a team launch: batch.hip).
+template <int MM, int NN>
+static int team_occupancy(size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&k_surfaces_fast<MM, NN, 1, 0, 4, 2>),
+                                                     kWave * 4, lds) != hipSuccess)
+        return 0;
+    return n;
+}
+int fused_team_blocks_per_cu(int M, int nm, int pal_stride) {
+    const size_t lds = fused_lds_bytes(4, M, pal_stride);
+    if (M == 4) return nm ? team_occupancy<4, 1>(lds) : team_occupancy<4, 0>(lds);
+    if (M == 8) return nm ? team_occupancy<8, 1>(lds) : team_occupancy<8, 0>(lds);
+    return nm ? team_occupancy<16, 1>(lds) : team_occupancy<16, 0>(lds);
+}
+
 // grid_blocks workgroups for fa.n_blocks FusedBlocks: equal (fa.queue == nullptr) or fewer, with the work queue.
 hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_waves, int grid_blocks, const FastTile *tiles,
                                  int n_tiles, const NodeArrays &na, const SideArrays &sa, const StepWeather *weather,

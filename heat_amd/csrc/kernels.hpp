@@ -27,6 +27,8 @@ void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, con
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
                             int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st);
 int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves, int pal_stride);
+// ... of a team variant, from the runtime's occupancy query for that very kernel (0: the query failed)
+int fused_team_blocks_per_cu(int M, int nm, int pal_stride);
 hipError_t launch_surfaces_fused(int M, int nm, int cav, int mixed, int max_waves, int grid_blocks, const FastTile *tiles, int n_tiles,
                                  const NodeArrays &na, const SideArrays &sa, const StepWeather *weather, int *flags,
                                  unsigned long long *nomass_iters, const FusedArgs &fa, hipStream_t st);

@@ -388,6 +388,7 @@ def test_shards_of_the_cluster_partition_march_without_any_exchange(oracle, n_ra
 
 @pytest.mark.parametrize("rooms,n,kw", [(8, 20, {}), (8, 20, dict(no_fusion=True)), (8, 32, {}), (6, 9, {}),
                                         (40, 20, {}), (40, 32, {}), (24, 13, dict(fuse_always=True)), (100, 16, {}),
+                                        (40, 7, dict(fuse_always=True, nodes_per_lane=4)),
                                         (16, 12, dict(fuse_always=True))])
 def test_buildings_of_small_rooms_joined_by_partitions(oracle, rooms, n, kw):
     """Buildings as models have them (src/model.rs:556-590: a partition is in the balance of both rooms it separates):
