@@ -413,6 +413,38 @@ def test_buildings_of_small_rooms_joined_by_partitions(oracle, rooms, n, kw):
         assert (b.n_fused_surfaces == md["n_surfaces"]) == fits, (b.n_fused_surfaces, b.class_counts())
 
 
+def test_teams_beside_short_calls_and_zone_lists_rebuilt(oracle):
+    """Clusters marched by teams of workgroups (layout.hpp, FusedSuper) in a batch large enough for the planner's own
+    rules (> 8192 surfaces): a call of two sub-timesteps streams the teams' mixed tiles (ThermalModel::march with
+    dt_subdivisions = 2 is the reference's validation setup), the next calls march them resident; the tile lists survive
+    heat_batch_set_shared_zones (a sharded host's call) with no zone shared, and sharing a team's zone is refused."""
+    md, st = mdl.partitioned_buildings(9600, 20, rooms=40, dt=45.0, seed=77)
+    Z = md["n_zones"]
+    rng = np.random.default_rng(3)
+    w = mdl.weather_series(15, 45.0, wind_speed=2.5, wind_deg=75.0)
+    a0 = rng.uniform(0., 60., Z)
+    b0 = rng.uniform(0.1, 2., Z)
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
+    assert rc == 0
+    got = st.copy()
+    with HeatBatch(md, use_graph=True) as b:
+        assert b.n_fused_surfaces == md["n_surfaces"]
+        b.upload_state(got)
+        b.march_resident(w[:2], a0, b0)               # streamed: fewer than three sub-timesteps
+        assert b.n_fused_launches == 0
+        b.march_resident(w[2:9], a0, b0)              # teams
+        assert b.n_fused_launches > 0
+        b.set_shared_zones(np.zeros(0, dtype=np.int32))   # nothing shared: the lists are rebuilt, teams stay
+        assert b.n_fused_surfaces == md["n_surfaces"]
+        b.march_resident(w[9:], a0, b0)
+        b.synchronize()
+        b.download_state(got)
+        with pytest.raises(HeatError):
+            b.set_shared_zones(np.array([5], dtype=np.int32))
+    assert_state_close(md, ref, got)
+
+
 @pytest.mark.parametrize("mode", ["planned", "streamed", "general"])
 def test_numerical_failure_names_the_surface(mode):
     """The reference's panic on a NaN convection coefficient names the values (surface.rs:704-707); the library
