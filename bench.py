@@ -210,7 +210,37 @@ def march_in_calls(march, weather, per_call):
         march(weather[i:i + per_call])
 
 
-def hbm_roofline(ab, surf_us, substep_us, n, counters, src, stale, kernel):
+def issue_view(counters, per_sub, surf_us):
+    """Instruction issue from the committed per-class counts of a workload: wave-instructions x cycles per class
+    (f64 4, every other VALU instruction 2) / (1024 SIMDs x 2.4 GHz x kernel time); `per_sub` scales the file's
+    per-launch counts to one sub-timestep of this run."""
+    valu = counters["valu_insts_per_launch"] * per_sub
+    issue = {"valu_insts_per_sub_timestep": valu}
+    cl = counters.get("counters_per_launch", {})
+    f64 = [cl.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+    meas = None
+    if all(v is not None for v in f64):
+        n64 = sum(f64) * per_sub
+        cyc = n64 * VALU_CYCLES_F64 + max(valu - n64, 0.0) * VALU_CYCLES_OTHER
+        issue.update({"f64_insts_per_sub_timestep": n64, "issue_cycles_per_sub_timestep": cyc,
+                      "frac": cyc / (surf_us * 1e-6) / SIMD_CYCLES_PER_SEC,
+                      "note": "measured wave-instructions by class (SQ_INSTS_VALU_*_F64 at 4 cycles, every other "
+                              "VALU instruction at 2) / (1024 SIMDs x 2.4 GHz x kernel time)"})
+        # the f64 flops the kernel really issued (adds and multiplies 1, FMAs 2, per lane of 64)
+        meas = (f64[0] + f64[1] + 2 * f64[2]) * 64 * per_sub / (surf_us * 1e-6) / 1e12
+    else:
+        cyc = valu * VALU_CYCLES_F64
+        issue.update({"issue_cycles_per_sub_timestep": cyc, "frac": cyc / (surf_us * 1e-6) / SIMD_CYCLES_PER_SEC,
+                      "note": "no per-class counts in the committed file: every VALU instruction booked at 4 cycles "
+                              "(an upper bound of the occupancy)"})
+    return issue, meas
+
+
+def hbm_roofline(ab, surf_us, substep_us, n, counters, src, stale, kernel, latency_bound=False):
+    """Streamed march against the HBM roofline (algorithmic bytes / kernel time). latency_bound: the
+    workload moves a tenth of the bytes the chip could (BASELINE config 5: 0.1 GB per sub-timestep of windows whose
+    no-mass loop re-evaluates the cavity's Nusselt correlations every pass, surface.rs:814) — the line then names the
+    instruction issue of the dependent chains as its bound and keeps the HBM figures beside it."""
     achieved = ab / (surf_us * 1e-6) / 1e9
     traffic = counters.get("hbm_traffic_bytes_per_launch") if (counters and not stale) else None
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -224,6 +254,20 @@ def hbm_roofline(ab, surf_us, substep_us, n, counters, src, stale, kernel):
             for k in ("SQ_WAIT_ANY_frac_of_wave_cycles", "SQ_ACTIVE_INST_VALU_frac_of_wave_cycles", "valu_insts_per_launch"):
                 if k in counters:
                     r[k] = counters[k]
+            r["issue"], meas = issue_view(counters, 1.0 / counters["workload"].get("substeps_per_launch", 1), surf_us)
+            if meas is not None:
+                r["measured_f64_tflops"] = meas
+            if traffic:
+                r["hbm_gbs_measured_traffic"] = traffic / (surf_us * 1e-6) / 1e9
+    if latency_bound:
+        r["hbm_frac"] = r["frac"]
+        r["bound_note"] = ("not an HBM-bound workload: %.2f GB of algorithmic bytes per sub-timestep; what bounds it is the "
+                           "latency of dependent f64 chains (Cavity::u_value and the Nusselt correlations inside the "
+                           "no-mass loop, two wavefronts per SIMD)" % (ab / 1e9))
+        if r.get("issue") and r["issue"].get("frac") is not None:
+            r.update({"bound": "valu_issue", "achieved": r["issue"]["issue_cycles_per_sub_timestep"] / (surf_us * 1e-6) / 1e9,
+                      "peak": SIMD_CYCLES_PER_SEC / 1e9, "unit": "Gcycle/s", "frac": r["issue"]["frac"],
+                      "hbm_achieved_gbs": achieved})
     return r
 
 
@@ -247,26 +291,10 @@ def fused_roofline(nodes_local, n_nodes_counted, P, surf_us, substep_us, n_sampl
     if counters and not stale:
         scale = nodes_local / counters["workload"]["nodes_total"]  # (a rank of a sharded run launches its share)
         per_sub = scale / counters["workload"]["substeps_per_launch"]
-        valu = counters["valu_insts_per_launch"] * per_sub
-        issue = {"valu_insts_per_sub_timestep": valu}
-        cl = counters.get("counters_per_launch", {})
-        f64 = [cl.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
-        if all(v is not None for v in f64):
-            n64 = sum(f64) * per_sub
-            cyc = n64 * VALU_CYCLES_F64 + max(valu - n64, 0.0) * VALU_CYCLES_OTHER
-            issue.update({"f64_insts_per_sub_timestep": n64, "issue_cycles_per_sub_timestep": cyc,
-                          "frac": cyc / (surf_us * 1e-6) / SIMD_CYCLES_PER_SEC,
-                          "note": "measured wave-instructions by class (SQ_INSTS_VALU_*_F64 at 4 cycles, every other "
-                                  "VALU instruction at 2) / (1024 SIMDs x 2.4 GHz x kernel time)"})
-            # the f64 flops the kernel really issued (adds and multiplies 1, FMAs 2, per lane of 64)
-            meas = (f64[0] + f64[1] + 2 * f64[2]) * 64 * per_sub / (surf_us * 1e-6) / 1e12
+        issue, meas = issue_view(counters, per_sub, surf_us)
+        if meas is not None:
             rl["measured_f64_tflops"] = meas
             rl["measured_f64_frac"] = meas / F64_PEAK_TFLOPS
-        else:
-            cyc = valu * VALU_CYCLES_F64
-            issue.update({"issue_cycles_per_sub_timestep": cyc, "frac": cyc / (surf_us * 1e-6) / SIMD_CYCLES_PER_SEC,
-                          "note": "no per-class counts in the committed file: every VALU instruction booked at 4 cycles "
-                                  "(an upper bound of the occupancy)"})
         rl["issue"] = issue
         t = counters.get("hbm_traffic_bytes_per_launch")
         if t:
@@ -365,16 +393,10 @@ def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
             counters, src, stale = committed_counters(config, int(md["n_surfaces"]), n_nodes, "streamed")
             res["roofline"] = hbm_roofline(ab, surf_us, substep_us, n_samples, counters, src, stale,
                                            "streamed march: k_surfaces_stream / k_surfaces_fast / k_surfaces_small "
-                                           "(iterate_surfaces: RK4 stencil + boundary updates, one sub-timestep per launch)")
+                                           "(iterate_surfaces: RK4 stencil + boundary updates, one sub-timestep per launch)",
+                                           latency_bound=config in ("5", "5x10"))
             # the same bytes over the wall-clock time of a step of the timed region (graph replay, launches and all)
             res["roofline"]["frac_wall_clock_step"] = ab / (elapsed / K) / 1e9 / HBM_PEAK_GBS
-            if config in ("5", "5x10"):
-                res["roofline"]["bound_note"] = (
-                    "config 5 moves 0.1 GB per sub-timestep: HBM is not what bounds it. Its time is the no-mass "
-                    "fixed-point loop of the glazing (Cavity::u_value + Nusselt correlations re-evaluated every pass, "
-                    "surface.rs:814): dependent f64 transcendental chains at 2 wavefronts per SIMD — a latency bound; "
-                    "the hbm line is kept for the contract's shape, SQ_WAIT / VALU-active fractions come from the "
-                    "committed counters when they are fresh")
         if main and not args.no_extras:
             # the drop-in call on a caller-owned host state (PCIe-inclusive; never `value`)
             st = state.copy()
