@@ -647,6 +647,26 @@ __device__ unsigned long long g_stamps[65536 * kStampsPerBlock];
 #else
 #define HEAT_STAMP(k, real) do { } while (0)
 #endif
+// Diagnostic build only (-DHEAT_STREAM_STAMPS -> lib/libheat_amd_sstamps.so; tools/stream_phases.py): lane 0 of every
+// STREAMED fast tile stamps the shader clock at the tile's phases — 0 start, 1 loads arrived, 6 boundary terms / no-mass
+// loop done, 7 RK4 done, 2 new convection coefficients and contributions done, 3 stores acknowledged — slot = tile index
+// (+ 32768 for tiles of 16 nodes per lane: the wide part has a list of its own).
+#ifdef HEAT_STREAM_STAMPS
+#ifndef HEAT_STAMPS
+constexpr int kStampsPerBlock = 8;
+__device__ unsigned long long g_stamps[65536 * kStampsPerBlock];
+#endif
+#define HEAT_SSTAMP(k, drain)                                                                                  \
+    do {                                                                                                       \
+        if constexpr (!FUSED && PAL) {                                                                         \
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+            if (lane == 0 && counter_index < 32768)                                                            \
+                g_stamps[(counter_index + (M == 16 ? 32768 : 0)) * kStampsPerBlock + (k)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                                      \
+    } while (0)
+#else
+#define HEAT_SSTAMP(k, drain) do { } while (0)
+#endif
 
 // One tile of a fast class: n_it sub-timesteps (one, unless FUSED) of its surfaces. The body of k_surfaces_fast and
 // of the fast-path cases of k_surfaces_stream.
@@ -667,6 +687,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     constexpr bool kVinLds = FUSED && M == 16;
     HEAT_STAMP(4, true);
     HEAT_STAMP(0, false);
+    HEAT_SSTAMP(0, false);
     double2 *const s_hT = fl.hT;
     double *const s_zT = fl.zT;
     (void)s_hT; (void)s_zT; (void)s_V; (void)s_pos; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
@@ -863,6 +884,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     StepWeather w_next = weather[step0];
 
     HEAT_STAMP(1, false);
+    HEAT_SSTAMP(1, true);
     // The side record: FUSED fetches it again for every sub-timestep (an L1/L2 hit) instead of holding its 20 registers
     // across the RK stages — at the END of the sub-timestep before, so that it travels while the zone balance is summed.
     SideConst c_cur = c_load;
@@ -1169,11 +1191,19 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         const double ULe = is_first ? hF : UL;
         const double qFe = is_first ? qF : 0.0;
         const double qBe = is_last ? qB : 0.0;
+#ifdef HEAT_STREAM_STAMPS
+        asm volatile("" : "+v"(T[0]), "+v"(T[M - 1]));
+        HEAT_SSTAMP(6, false);
+#endif
         if (full) {
             rk4_horner<M>(T, Vat, U, ULe, is_first, is_last, qFe, [&](int j) -> double { return (j == M - 1) ? qBe : 0.0; });
         } else {
             rk4_horner<M>(T, Vat, U, ULe, is_first, is_last, qFe, [&](int j) -> double { return (j == jl) ? qBe : 0.0; });
         }
+#ifdef HEAT_STREAM_STAMPS
+        asm volatile("" : "+v"(T[0]), "+v"(T[M - 1]));
+        HEAT_SSTAMP(7, false);
+#endif
         if constexpr (FUSED) {  // U lives on: back to UValue::Back at the last node
             if (full) {
                 U[M - 1] = is_last ? 0.0 : U[M - 1];
@@ -1247,6 +1277,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     }
     }  // sub-timesteps
     HEAT_STAMP(2, false);
+    HEAT_SSTAMP(2, false);
 
     if constexpr (FUSED) {
         if (active) {
@@ -1273,6 +1304,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores acknowledged: what a retiring wavefront waits for)
 #endif
     HEAT_STAMP(3, false);
+    HEAT_SSTAMP(3, true);
     HEAT_STAMP(5, true);
     if constexpr (NM) {
         // passes of the no-mass loop, summed per tile (one owner per slot: no atomics on a shared word)
@@ -2281,7 +2313,7 @@ void launch_set_step(int *step_ptr, int v, int last, hipStream_t st) {
 
 }  // namespace heat
 
-#ifdef HEAT_STAMPS
+#if defined(HEAT_STAMPS) || defined(HEAT_STREAM_STAMPS)
 extern "C" int heat_debug_stamps(unsigned long long *dst, int n_blocks) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(heat::g_stamps), (size_t)n_blocks * heat::kStampsPerBlock * sizeof(unsigned long long));
 }

@@ -120,7 +120,9 @@ struct SideArrays {
 //   bits 0-3  index of V; 14 and 15 mark the first node of a no-mass chunk of one / of two nodes (V = 0)
 //   bits 4-6  index of U
 // The batch's palettes are stored in the width its walls need (NodeArrays::pal_stride, pal_ubase):
-//   narrow  8 V + 4 U = 12 doubles (96 bytes per surface): walls of up to three layers — the synthetic workloads
+//   tiny    4 V + 4 U =  8 doubles (64 bytes per surface): walls of one or two materials (three distinct V and U besides
+//          the 0.0 of entry 0) — BASELINE config 3 and the uniform headline; 32 bytes per surface less to stream
+//   narrow  8 V + 4 U = 12 doubles (96 bytes per surface): walls of up to three layers
 //   wide   16 V + 8 U = 24 doubles (192 bytes per surface): up to 13 distinct V and 7 distinct U — walls of six
 //          different layers (render / brick / insulation / block / service gap / plaster) stay in palette form, and
 //          with it candidates for the cluster-resident march
@@ -130,6 +132,9 @@ constexpr int kPal = kPalV + kPalU;
 constexpr int kPalVNarrow = 8;
 constexpr int kPalUNarrow = 4;
 constexpr int kPalNarrow = kPalVNarrow + kPalUNarrow;
+constexpr int kPalVTiny = 4;
+constexpr int kPalUTiny = 4;
+constexpr int kPalTiny = kPalVTiny + kPalUTiny;
 constexpr int kPalVMark1 = 14;       // V index values that are chunk marks; V entries usable: 0 .. 13
 constexpr int kPalUShift = 4;
 

@@ -58,6 +58,7 @@ struct Category {
     int m_ok;  // fast: blocking factors whose lanes hold every chunk whole (bit 0: 4, bit 1: 8, bit 2: 16 nodes per lane)
     int chunky = 0;  // fast: has chunks other than one-node facings (inside the wall, or of two nodes)
     int wide = 0;    // fast, palette form: needs the wide palette (more than 8 V or 4 U entries, with the 0.0 of entry 0)
+    int tiny = 0;    // fast, palette form: fits the tiny palette (4 V and 4 U entries at most)
 };
 inline int m_bit(int M) { return M == 4 ? 1 : (M == 8 ? 2 : 4); }
 
@@ -144,6 +145,7 @@ Category categorize(const heat_batch_desc *d, int64_t s, int n, const heat_batch
     r.m_ok = m_ok;
     r.chunky = (nm && !facings_only) ? 1 : 0;
     r.wide = (pal && (nv > kPalVNarrow || nu > kPalUNarrow)) ? 1 : 0;
+    r.tiny = (pal && nv <= kPalVTiny && nu <= kPalUTiny) ? 1 : 0;
     return r;
 }
 
@@ -796,10 +798,14 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
     std::vector<double> hV(node_cursor, 0.0), hU(node_cursor, 0.0);
     std::vector<uint8_t> hCls(p.n_palette ? node_cursor : 0, 0);
     // the palette width of the batch (layout.hpp): narrow unless a palette-form wall needs more entries
-    p.pal_stride = kPalNarrow;
+    static const bool tiny_off = getenv("HEAT_AMD_NO_TINY_PAL") != nullptr;  // measurement
+    p.pal_stride = tiny_off ? kPalNarrow : kPalTiny;
     for (int64_t s = 0; s < S; s++)
-        if (placed[s].cls < kNumFast && kFastPAL[placed[s].cls] && cat[s].wide) p.pal_stride = kPal;
-    p.pal_ubase = (p.pal_stride == kPal) ? kPalV : kPalVNarrow;
+        if (placed[s].cls < kNumFast && kFastPAL[placed[s].cls]) {
+            if (cat[s].wide) p.pal_stride = kPal;
+            else if (!cat[s].tiny) p.pal_stride = std::max(p.pal_stride, kPalNarrow);
+        }
+    p.pal_ubase = (p.pal_stride == kPal) ? kPalV : (p.pal_stride == kPalNarrow ? kPalVNarrow : kPalVTiny);
     const int pstride = p.pal_stride, ubase = p.pal_ubase;
     std::vector<double> hPal(p.n_palette ? (size_t)S * pstride : 0, 0.0);
     const int64_t gen_slots = node_cursor - p.gen_base;
@@ -1185,7 +1191,8 @@ int check_plan(const Plan &p, const heat_batch_desc *d, std::string &err) {
     PLAN_REQUIRE((int64_t)p.side.size() == 2 * S && (int64_t)p.meta.size() == S, "side / meta size");
     PLAN_REQUIRE((int64_t)p.V.size() == p.node_slots && (int64_t)p.U.size() == p.node_slots, "V / U size");
     PLAN_REQUIRE(p.cls.empty() || (int64_t)p.cls.size() == p.node_slots, "class bytes size");
-    PLAN_REQUIRE((p.pal_stride == kPalNarrow && p.pal_ubase == kPalVNarrow) || (p.pal_stride == kPal && p.pal_ubase == kPalV),
+    PLAN_REQUIRE((p.pal_stride == kPalTiny && p.pal_ubase == kPalVTiny) || (p.pal_stride == kPalNarrow && p.pal_ubase == kPalVNarrow) ||
+                     (p.pal_stride == kPal && p.pal_ubase == kPalV),
                  "palette stride %d, U entries from %d", p.pal_stride, p.pal_ubase);
     PLAN_REQUIRE(p.pal.empty() || (int64_t)p.pal.size() == S * p.pal_stride, "palette size");
     // tiles: every device surface in exactly one tile; node ranges inside the buffers and disjoint

@@ -835,9 +835,15 @@ def test_walls_of_many_materials_keep_the_palette_and_the_resident_march(oracle)
             dict(thickness=0.08, k=0.25, rho=600., cp=1000.), dict(thickness=0.14, k=0.51, rho=1400., cp=1000.),
             dict(thickness=0.06, k=1.4, rho=2100., cp=880.), dict(thickness=0.015, k=0.4, rho=1000., cp=1000.)]
     mats = [dict(L, front_thermal_abs=0.9, back_thermal_abs=0.9, front_solar_abs=0.6, back_solar_abs=0.6) for L in mats]
-    for nl, copies in ((5, 96), (6, 64)):
+    # (three materials: more distinct V = dt / C than the TINY palette of 4 + 4 entries holds, the batch stores the
+    # narrow 8 + 4; one or two materials — most other tests — take the tiny one)
+    for nl, copies in ((3, 96), (5, 96), (6, 64)):
         d = oracle.discretize(mats[:nl], 600., 0.03, 60., 1., math.pi / 2)
-        assert len(set(np.round(d["uvalue"], 12))) > 4, d["uvalue"]       # (entry 0 of the palette is 0.0)
+        if nl >= 5:
+            assert len(set(np.round(d["uvalue"], 12))) > 4, d["uvalue"]   # (entry 0 of the palette is 0.0)
+        else:
+            nv = len(set(np.round(600. / d["tstep_subdivision"] / d["mass"][d["mass"] >= 1e-5], 9)))
+            assert 4 <= nv <= 7 and len(set(np.round(d["uvalue"], 12))) <= 4, (nv, d["uvalue"])
         assert not oracle.get_chunks(d["mass"])[1]                         # all massive
         dt = 600. / d["tstep_subdivision"]
         md, st = surfaces_model(d, dt, mdl.OUTDOOR, mdl.SPACE, n_zones=4, zone_volume=[60.] * 4, front_emis=0.9,
