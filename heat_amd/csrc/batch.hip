@@ -207,6 +207,7 @@ struct heat_batch {
     // ... in three parts, one per variant of the kernel (kernels.hip: 16 nodes per lane | 8 / 4 nodes per lane and small
     // surfaces | tiles with no-mass chunks other than facings), launched back to back: [part] = first tile, tiles
     int ulist_part[2][kStreamVariants][2] = {};
+    unsigned int sweep_parity = 0;  // enqueue_surfaces: direction of the next streamed sweep (zig-zag)
     bool class_has_chunks[kNumFast] = {};  // the class holds tiles with such chunks: its own launch takes the NM = 2 variant
     bool in_ulist[2][kNumFast] = {};
     bool small_in_ulist[2] = {false, false};
@@ -719,6 +720,11 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     // classes it does not hold follow on their own.
     const int ul = streamed_only ? 0 : 1;
     const bool unified = b->n_ulist[ul] > 0;
+    // Zig-zag sweeps: consecutive sub-timesteps walk the batch in opposite directions. A sweep streams the whole state
+    // through the 256 MB memory-side cache (MI355X: Infinity Cache in front of HBM); walked in the same direction every
+    // time, nothing of it is left when its turn comes again — walked back, the last quarter of a 1 GB sweep is.
+    static const bool zigzag_off = getenv("HEAT_AMD_NO_ZIGZAG") != nullptr;  // measurement
+    const int rev = (!zigzag_off && (b->sweep_parity++ & 1)) ? 1 : 0;
     int n_small_plain = b->n_small_plain_tiles;
     if (unified) {
         for (int c = 0; c < kNumFast; c++) if (b->in_ulist[ul][c]) nt[c] = 0;
@@ -757,12 +763,13 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         static const int order_env = getenv("HEAT_AMD_STREAM_ORDER") ? atoi(getenv("HEAT_AMD_STREAM_ORDER")) : 0;  // measurement
         const int seq[2][kStreamVariants] = {{3, 1, 2, 0}, {0, 1, 2, 3}};
         for (int qi = 0; qi < kStreamVariants; qi++) {
-            const int q = seq[order_env ? 1 : 0][qi];
+            // (a reversed sweep takes the parts in the opposite order too, each from its end)
+            const int q = seq[order_env ? 1 : 0][rev ? kStreamVariants - 1 - qi : qi];
             const int first = b->ulist_part[ul][q][0], n = b->ulist_part[ul][q][1];
             if (n > 0)
                 launch_surfaces_stream(q, b->d_ulist[ul].p + first, n, b->na, b->gen_base, b->sa, b->d_weather.p, b->d_step.p,
                                        step_fixed, b->d_zone_T.p, b->d_flags.p,
-                                       b->d_ucount.p + ul * b->ucount_stride + first, b->n_cu, us);
+                                       b->d_ucount.p + ul * b->ucount_stride + first, b->n_cu, us, rev);
         }
     }
     // work of each class in node slots, to size the persistent grids
@@ -782,7 +789,7 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
         launch_surfaces_fast(kFastM[c], kFastNM[c] ? (b->class_has_chunks[c] ? 2 : 1) : 0, kFastPAL[c], kFastCAV[c], work[c] / total_work,
                              b->d_fast_tiles[c].p, nt[c], b->na,
                              b->sa, b->d_weather.p, b->d_step.p, step_fixed, b->d_zone_T.p, b->d_flags.p,
-                             b->d_nomass_iters.p + b->nm_count_base[c], b->n_cu, next_stream());
+                             b->d_nomass_iters.p + b->nm_count_base[c], b->n_cu, next_stream(), rev);
     }
     unsigned long long *cnt = b->d_nomass_iters.p + b->nm_count_base[kNumFast];
     if (n_small_plain > 0)

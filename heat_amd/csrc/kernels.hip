@@ -1420,8 +1420,13 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
         }
         wave = blk.first_tile + wib;
     }
-    fast_tile_march<M, NM, PAL, CAV, FUSED, SMALL>(tiles[wave], wave, true, lane, wib, s_pal, s_V, s_pos_static, fl, blk, blk_waves, n_it, step0, na,
+    // (streamed: consecutive sub-timesteps walk the list in opposite directions — what the last sweep touched last is
+    // what this one reads first, out of the memory-side cache instead of HBM)
+    {
+    const int tix = (!FUSED && fa.reverse) ? n_tiles - 1 - wave : wave;
+    fast_tile_march<M, NM, PAL, CAV, FUSED, SMALL>(tiles[tix], tix, true, lane, wib, s_pal, s_V, s_pos_static, fl, blk, blk_waves, n_it, step0, na,
                                                    sd, weather, zone_T, flags, nomass_iters, fa, write_out, team);
+    }
 next_block:
     if constexpr (FUSED) {
         if constexpr (kTeam) {
@@ -1471,7 +1476,7 @@ __global__ void __launch_bounds__(256, VARIANT == kStreamLight ? 3 : 2)
 k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, int64_t gen_base, SideArrays sd,
                   const StepWeather *__restrict__ weather, const int *__restrict__ step_ptr, int step_fixed,
                   const double *__restrict__ zone_T, int *__restrict__ flags,
-                  unsigned long long *__restrict__ nomass_iters) {
+                  unsigned long long *__restrict__ nomass_iters, int reverse) {
     extern __shared__ double s_pal[];  // 4 * kWave * na.pal_stride doubles
     __shared__ double s_pos[4 * kWave];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1486,11 +1491,15 @@ k_surfaces_stream(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na
     if (wave0 >= n_tiles) return;
     constexpr int kNm = VARIANT == kStreamChunks ? 2 : 1;
     // (the tile descriptor is wave-uniform: scalar loads; the next one is fetched a whole tile ahead of its use)
-    FastTile tile_next = tiles[__builtin_amdgcn_readfirstlane(wave0)];
+    // reverse: the list from its end — consecutive sub-timesteps sweep the batch in opposite directions, so that what the
+    // last sweep touched last (still in the 256 MB memory-side cache) is what this one reads first
+    const int last = n_tiles - 1;
+    FastTile tile_next = tiles[__builtin_amdgcn_readfirstlane(reverse ? last - wave0 : wave0)];
     for (int wv = wave0; wv < n_tiles; wv += n_waves) {
-        const int w = __builtin_amdgcn_readfirstlane(wv);
+        const int w = __builtin_amdgcn_readfirstlane(reverse ? last - wv : wv);
         FastTile tile = tile_next;
-        tile_next = tiles[__builtin_amdgcn_readfirstlane(min(wv + n_waves, n_tiles - 1))];
+        const int wn = min(wv + n_waves, last);
+        tile_next = tiles[__builtin_amdgcn_readfirstlane(reverse ? last - wn : wn)];
         const int kind = (tile.k >> kTileKindShift) & 3;
         const bool nm = (tile.k & kTileNmBit) != 0;
         tile.k = (int16_t)(tile.k & (0x1ff | kTileMixedBit | kTileChunkyBit));
@@ -2055,7 +2064,7 @@ static inline size_t pal_lds_bytes(const NodeArrays &na) { return (size_t)4 * kW
 void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
                           const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
-                          const double *zone_T, int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st) {
+                          const double *zone_T, int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st, int reverse) {
     if (n_tiles <= 0) return;
     // persistent grid: as many 4-wave blocks as the chip holds at this kernel's occupancy (waves per SIMD by
     // VGPR count: M = 4 -> 5, M = 8 -> 3, M = 16 -> 2), capped by the number of tiles; n_cu: compute units of the
@@ -2069,7 +2078,8 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
     // (M = 4 tiles are too small for it: 1 M x 20 nodes ran 172 us persistent vs 155 us one wave per tile.)
     const bool persistent = tune > 0 && grid_share > 0.999 && M >= 8;
     const dim3 grid(persistent ? std::min(full_grid, n_cu * blocks_per_cu) : full_grid), block(256);
-    const FusedArgs no_fa{};
+    FusedArgs no_fa{};
+    no_fa.reverse = reverse;
 #define HEAT_LAUNCH_FAST(MM, NN, PP, CC)                                                                          \
     hipLaunchKernelGGL((k_surfaces_fast<MM, NN, PP, CC, 0>), grid, block, PP ? pal_lds_bytes(na) : 0, st, tiles, n_tiles, na, sa, weather, \
                        step_ptr, step_fixed, zone_T, flags, nomass_iters, no_fa)
@@ -2090,14 +2100,14 @@ void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, co
 // grid: persistent — as many 4-wave blocks per compute unit as the variant's launch bounds admit — capped by the tile count.
 void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
-                            int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st) {
+                            int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st, int reverse) {
     if (n_tiles <= 0) return;
     static const int per_cu_env = getenv("HEAT_AMD_STREAM_BLOCKS") ? atoi(getenv("HEAT_AMD_STREAM_BLOCKS")) : 0;
     const int per_cu = per_cu_env > 0 ? per_cu_env : (variant == kStreamLight ? 3 : 2);
     const int grid = std::min(blocks_for_waves(n_tiles), n_cu * per_cu);
 #define HEAT_LAUNCH_STREAM(V)                                                                                       \
     hipLaunchKernelGGL(k_surfaces_stream<V>, dim3(grid), dim3(256), pal_lds_bytes(na), st, tiles, n_tiles, na, gen_base, sa, weather, \
-                       step_ptr, step_fixed, zone_T, flags, nomass_iters)
+                       step_ptr, step_fixed, zone_T, flags, nomass_iters, reverse)
     if (variant == kStreamWide) HEAT_LAUNCH_STREAM(kStreamWide);
     else if (variant == kStreamLight) HEAT_LAUNCH_STREAM(kStreamLight);
     else if (variant == kStreamChunks) HEAT_LAUNCH_STREAM(kStreamChunks);

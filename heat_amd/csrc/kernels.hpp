@@ -14,7 +14,7 @@ struct SlotArrays {
 void launch_surfaces_fast(int M, int nm, int pal, int cav, double grid_share, const FastTile *tiles, int n_tiles,
                           const NodeArrays &na,
                           const SideArrays &sa, const StepWeather *weather, const int *step_ptr, int step_fixed,
-                          const double *zone_T, int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st);
+                          const double *zone_T, int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st, int reverse = 0);
 // Tile kinds of the unified streamed list (FastTile::k, bits 9-11; k_surfaces_stream)
 constexpr int kStreamKindShift = 9;
 constexpr int kStreamKindSmall = 3;
@@ -25,7 +25,7 @@ constexpr int kStreamNmBit = 1 << 11;
 constexpr int kStreamVariants = 4;
 void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, const NodeArrays &na, int64_t gen_base, const SideArrays &sa,
                             const StepWeather *weather, const int *step_ptr, int step_fixed, const double *zone_T,
-                            int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st);
+                            int *flags, unsigned long long *nomass_iters, int n_cu, hipStream_t st, int reverse = 0);
 int fused_blocks_per_cu(int M, int cav, int mixed, int max_waves, int pal_stride);
 // ... of a team variant, from the runtime's occupancy query for that very kernel (0: the query failed)
 int fused_team_blocks_per_cu(int M, int nm, int pal_stride);
