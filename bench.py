@@ -204,6 +204,26 @@ def committed_counters(config, surfaces, nodes_total, mode, substeps=1):
     return best
 
 
+def rocprof_kernel_us(counters_src, kernel_substr):
+    """Mean duration of the streamed surface kernel(s) of a sub-timestep from the rocprofv3 --kernel-trace --stats summary
+    committed beside a counters file (tools/profile_bundle.sh writes both in one go: profiles/<tag>_<name>_kernel_stats.csv
+    next to profiles/<tag>_<name>_<mode>_counters.json): the sum over the variants whose name holds `kernel_substr`.
+    HIP events around a sub-timestep's launches book the few microseconds between them as kernel time; this does not."""
+    if not counters_src:
+        return None
+    import csv
+    base = os.path.basename(counters_src)
+    parts = base.split("_")          # r03_cfg3_streamed_counters.json -> r03_cfg3_kernel_stats.csv
+    f = os.path.join(ROOT, "profiles", "_".join(parts[:-2]) + "_kernel_stats.csv")
+    if not os.path.exists(f):
+        return None
+    tot = 0.0
+    for r in csv.DictReader(open(f)):
+        if kernel_substr in r["Name"]:
+            tot += float(r["AverageNs"]) / 1e3
+    return tot or None
+
+
 def march_in_calls(march, weather, per_call):
     """K sub-timesteps as march calls of `per_call` sub-timesteps (ThermalModel::march = one call)."""
     for i in range(0, len(weather), per_call):
@@ -259,6 +279,15 @@ def hbm_roofline(ab, surf_us, substep_us, n, counters, src, stale, kernel, laten
                 r["measured_f64_tflops"] = meas
             if traffic:
                 r["hbm_gbs_measured_traffic"] = traffic / (surf_us * 1e-6) / 1e9
+            ks = counters.get("kernel", "")
+            rk = rocprof_kernel_us(src, ks.split("<")[0] + ("<" + ks.split("<")[1] if "<" in ks else ""))
+            if rk:
+                r["kernel_us_rocprof"] = rk
+                r["frac_rocprof"] = ab / (rk * 1e-6) / 1e9 / HBM_PEAK_GBS
+                r["kernel_us_note"] = ("kernel_us: HIP events around the launches of a sub-timestep, live (they include the gap "
+                                       "between its kernels when launched outside a graph); kernel_us_rocprof: sum of the "
+                                       "kernels' mean durations in the committed rocprofv3 --kernel-trace --stats of this "
+                                       "workload, same kernel sources")
     if latency_bound:
         r["hbm_frac"] = r["frac"]
         r["bound_note"] = ("not an HBM-bound workload: %.2f GB of algorithmic bytes per sub-timestep; what bounds it is the "
