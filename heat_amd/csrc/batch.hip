@@ -135,7 +135,10 @@ struct DevBuf {
     }
 };
 
-constexpr int kFusedMinSubsteps = 3;  // march calls of fewer sub-timesteps are streamed (large batches)
+// march calls of fewer sub-timesteps are streamed (large batches). Round 3, 1 M x 32 on one MI355X (tools/short_calls.py): a
+// cluster-resident call costs 155 us + 59 us per sub-timestep, the same batch streamed 198-212 us per sub-timestep (its layout
+// pads every cluster to whole wavefronts; laid out for streaming alone it takes 166-188) -> resident from two sub-timesteps on.
+static const int kFusedMinSubsteps = getenv("HEAT_AMD_FUSED_MIN") ? atoi(getenv("HEAT_AMD_FUSED_MIN")) : 2;
 
 }  // namespace
 
@@ -208,6 +211,7 @@ struct heat_batch {
     // surfaces | tiles with no-mass chunks other than facings), launched back to back: [part] = first tile, tiles
     int ulist_part[2][kStreamVariants][2] = {};
     unsigned int sweep_parity = 0;  // enqueue_surfaces: direction of the next streamed sweep (zig-zag)
+    unsigned int fused_parity = 0;  // enqueue_fused: direction of the next cluster-resident launch
     bool class_has_chunks[kNumFast] = {};  // the class holds tiles with such chunks: its own launch takes the NM = 2 variant
     bool in_ulist[2][kNumFast] = {};
     bool small_in_ulist[2] = {false, false};
@@ -832,6 +836,10 @@ void enqueue_zones(heat_batch *b, int mode) {
 // streamed_beside: other surfaces of the batch are streamed on the batch's stream while this launch runs.
 int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside = false) {
     FusedArgs fa{};
+    {   // zig-zag over march calls (see enqueue_surfaces): what the last call wrote back last is this call's first read
+        static const bool zigzag_off = getenv("HEAT_AMD_NO_ZIGZAG") != nullptr;  // measurement
+        fa.reverse = (!zigzag_off && (b->fused_parity++ & 1)) ? 1 : 0;
+    }
     fa.zones = b->d_fzones.p;
     fa.zone_eoff = b->d_fzone_eoff.p;
     fa.slots = b->d_fslots.p;
@@ -1686,8 +1694,8 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     }
     // Cluster-resident march: the fused workgroups march all n_sub sub-timesteps in one launch per class (on a
     // side stream when other surfaces are streamed beside them); whatever is not fused is streamed as before.
-    // (a fused launch costs about as much as three streamed sub-timesteps before its first sub-timestep is done —
-    // measured, 1 M x 32: 341 / 198 / 113 us per sub-timestep at 1 / 2 / 5 per call against 171 streamed)
+    // (a resident call costs about 150 us + 59 us per sub-timestep at 1 M x 32 — round 3, tools/short_calls.py: 262 / 144 / 108 /
+    // 88 us per sub-timestep at 1 / 2 / 3 / 5 per call against 206 for the same batch streamed: resident from two on)
     const bool fused = b->any_fused && b->fusion_on && n_sub >= (b->n_surf <= 8192 ? 1 : kFusedMinSubsteps);
     bool streamed = !fused;
     if (fused) {

@@ -1389,7 +1389,7 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     for (int wave = wave0; FUSED ? (kTeam ? (sb < fa.n_super) : (bi < fa.n_blocks)) : (wave < n_tiles); wave += n_waves) {
     if constexpr (FUSED) {
         if constexpr (kTeam) {
-            const FusedSuper su = fa.supers[sb];
+            const FusedSuper su = fa.supers[fa.reverse ? fa.n_super - 1 - sb : sb];  // (every member maps alike)
             if (team.member >= su.n_members) {  // (the whole workgroup: this cluster has fewer members than a team)
                 sb += n_teams;
                 team.round++;
@@ -1397,7 +1397,10 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
             }
             bi = su.first_block + team.member;
         }
-        blk = fa.blocks[bi];
+        // (reverse: the list from its end — consecutive march calls take the workgroups' clusters in opposite orders, so
+        // that the temperatures the last call wrote last are read first, out of the memory-side cache; team members
+        // are named by their cluster and stay as they are)
+        blk = fa.blocks[(!kTeam && fa.reverse) ? fa.n_blocks - 1 - bi : bi];
         blk_waves = blk.n_tiles + (SMALL == 1 ? blk.n_small : 0);
         const bool looping = kTeam || fa.queue != nullptr;  // the workgroup goes on to another block after this one
         if (wib >= blk_waves) {

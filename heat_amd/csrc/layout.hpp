@@ -211,7 +211,7 @@ struct FusedArgs {
     int32_t n_super;
     uint32_t tag_base;                   // launch number << 22 (tag = tag_base | round << 12 | sub-timestep + 1)
     int32_t team_size;                   // workgroups per team in this launch: the most members a cluster of the list has
-    int32_t reverse;     // streamed launches only (FUSED = 0): walk the tile list from its end (zig-zag sweeps, batch.hip)
+    int32_t reverse;     // walk the tile list (streamed launches) / the block or cluster list (cluster-resident) from its end: zig-zag sweeps, batch.hip
 };
 
 // Clusters larger than a workgroup (a building whose rooms are all joined by interior walls): a TEAM of up to

@@ -276,7 +276,7 @@ int heat_batch_comm_destroy(heat_batch *b);
  * could not complete that exchange returns HEAT_E_DEVICE). Everything else is streamed one sub-timestep per launch. The zone sums (here and in the streamed k_zones) are lane-strided partial sums followed
  * by a fixed reduction tree: deterministic run to run, but NOT the sequential surface order of model.rs:562-585 — the
  * results differ from a sequential sum by rounding (~1e-16 relative; everything is tested at 1e-9 against the oracle).
- * March calls of fewer than three sub-timesteps are streamed as well (the fused launch only pays off from three on).
+ * March calls of a single sub-timestep are streamed as well (the fused launch pays off from two on).
  * heat_batch_set_fusion(b, 0) streams everything (used to measure the per-sub-timestep kernel on its own). */
 int heat_batch_set_fusion(heat_batch *b, int32_t enabled);
 int64_t heat_batch_n_fused_surfaces(const heat_batch *b);

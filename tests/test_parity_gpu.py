@@ -30,8 +30,8 @@ def run_both(oracle, md, state0, weather, a0=None, b0=None, **opts):
         counts = b.class_counts()
         gpu_iters = b.nomass_iterations()
         n_fused = b.n_fused_surfaces
-        # (a planned cluster-resident march must really have run: calls of >= 3 sub-timesteps, or any in a small batch)
-        assert (b.n_fused_launches > 0) == (n_fused > 0 and (len(weather) >= 3 or md["n_surfaces"] <= 8192))
+        # (a planned cluster-resident march must really have run: calls of >= 2 sub-timesteps, or any in a small batch)
+        assert (b.n_fused_launches > 0) == (n_fused > 0 and (len(weather) >= 2 or md["n_surfaces"] <= 8192))
     if n_fused > 0 and "no_fusion" not in opts:
         # the planner sent (part of) this batch through the cluster-resident march: the streamed kernels of the
         # same batch are held to the same oracle
@@ -415,8 +415,9 @@ def test_buildings_of_small_rooms_joined_by_partitions(oracle, rooms, n, kw):
 
 def test_teams_beside_short_calls_and_zone_lists_rebuilt(oracle):
     """Clusters marched by teams of workgroups (layout.hpp, FusedSuper) in a batch large enough for the planner's own
-    rules (> 8192 surfaces): a call of two sub-timesteps streams the teams' mixed tiles (ThermalModel::march with
-    dt_subdivisions = 2 is the reference's validation setup), the next calls march them resident; the tile lists survive
+    rules (> 8192 surfaces): a call of one sub-timestep streams the teams' mixed tiles (a resident launch pays from two
+    sub-timesteps on, batch.hip kFusedMinSubsteps), the next calls — one of two sub-timesteps, ThermalModel::march with
+    dt_subdivisions = 2 is the reference's validation setup — march them resident; the tile lists survive
     heat_batch_set_shared_zones (a sharded host's call) with no zone shared, and sharing a team's zone is refused."""
     md, st = mdl.partitioned_buildings(9600, 20, rooms=40, dt=45.0, seed=77)
     Z = md["n_zones"]
@@ -431,10 +432,13 @@ def test_teams_beside_short_calls_and_zone_lists_rebuilt(oracle):
     with HeatBatch(md, use_graph=True) as b:
         assert b.n_fused_surfaces == md["n_surfaces"]
         b.upload_state(got)
-        b.march_resident(w[:2], a0, b0)               # streamed: fewer than three sub-timesteps
+        b.march_resident(w[:1], a0, b0)               # streamed: a single sub-timestep
         assert b.n_fused_launches == 0
-        b.march_resident(w[2:9], a0, b0)              # teams
-        assert b.n_fused_launches > 0
+        b.march_resident(w[1:3], a0, b0)              # teams, two sub-timesteps
+        n2 = b.n_fused_launches
+        assert n2 > 0
+        b.march_resident(w[3:9], a0, b0)              # teams (the other direction through the clusters)
+        assert b.n_fused_launches > n2
         b.set_shared_zones(np.zeros(0, dtype=np.int32))   # nothing shared: the lists are rebuilt, teams stay
         assert b.n_fused_surfaces == md["n_surfaces"]
         b.march_resident(w[9:], a0, b0)
