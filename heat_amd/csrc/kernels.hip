@@ -459,6 +459,49 @@ __device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const Fu
     __syncthreads();
 }
 
+// The same, from values fetched ahead (fast_tile_march, FUSED): a workgroup's first microseconds are a chain of memory
+// round trips — block -> tile -> records / T / palettes -> zone list -> zone data — and every workgroup pays it once per march
+// call (8.7 % of its life at 20 sub-timesteps per call, 28 % at 5: profiles/r03_fused_phases.txt). The zone list depends on
+// the block alone and travels beside the tile descriptor, the zone data beside the tile's own loads.
+struct FusedPre {
+    int e_first, n_e, zoff, z, slot0;
+    double zT, za0, zb0, zvol;
+};
+__device__ __forceinline__ void fused_pre_a(const FusedBlock &blk, const FusedArgs &fa, FusedPre &p) {
+    p = FusedPre{0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
+    const int nz = blk.n_zones;
+    if (nz > 0) {  // (uniform: a block of surfaces that face no zone has no list)
+        p.e_first = fa.zone_eoff[blk.first_zone];
+        p.n_e = fa.zone_eoff[blk.first_zone + nz];
+        p.zoff = fa.zone_eoff[blk.first_zone + min((int)threadIdx.x, nz)];
+        p.z = fa.zones[blk.first_zone + min((int)threadIdx.x, nz - 1)];
+    }
+}
+__device__ __forceinline__ void fused_pre_b(const FusedBlock &blk, const FusedArgs &fa, FusedPre &p) {
+    if (blk.n_zones > 0) {
+        p.n_e -= p.e_first;
+        p.zoff -= p.e_first;
+        p.zT = fa.zone_T[p.z];
+        p.za0 = fa.a0[p.z];
+        p.zb0 = fa.b0[p.z];
+        p.zvol = fa.vol[p.z];
+        if (p.n_e > 0) p.slot0 = fa.slots[p.e_first + min((int)threadIdx.x, p.n_e - 1)];
+    }
+}
+__device__ __forceinline__ void fused_block_init(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int n_threads,
+                                                 const FusedPre &p) {
+    if ((int)threadIdx.x <= blk.n_zones) l.zoff[threadIdx.x] = p.zoff;
+    if ((int)threadIdx.x < blk.n_zones) {
+        l.zT[threadIdx.x] = p.zT;
+        l.za0[threadIdx.x] = p.za0;
+        l.zb0[threadIdx.x] = p.zb0;
+        l.zvol[threadIdx.x] = p.zvol;
+    }
+    if ((int)threadIdx.x < p.n_e) l.slots[p.slot0] = (unsigned short)threadIdx.x;
+    for (int e = threadIdx.x + n_threads; e < p.n_e; e += n_threads) l.slots[fa.slots[p.e_first + e]] = (unsigned short)e;
+    __syncthreads();
+}
+
 // calculate_zones_abc + estimate_zones_future_temperatures for the block's zones (model.rs:489-597,650-674): the sides'
 // (hs A, T) pairs are in LDS. A workgroup with no more zones than wavefronts gives every zone a wavefront (k_zones'
 // summation tree). One with more zones (buildings: rooms joined by partitions, a dozen walls each) gives every zone
@@ -691,6 +734,9 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
     double2 *const s_hT = fl.hT;
     double *const s_zT = fl.zT;
     (void)s_hT; (void)s_zT; (void)s_V; (void)s_pos; (void)nm_on; (void)blk; (void)blk_waves; (void)counter_index;
+    FusedPre pre;
+    (void)pre;
+    if constexpr (FUSED) fused_pre_a(blk, fa, pre);  // (beside the tile descriptor: both depend on the block alone)
     const bool mixed = PAL && (tile.k & kTileMixedBit) != 0;  // (wave-uniform) surfaces of different lane counts
     // (wave-uniform) the tile holds no-mass chunks other than one-node facings: chunks inside the wall, of two nodes
     // (streamed variants only: the cluster-resident march leaves clusters with such walls to the streamed kernels — the
@@ -773,21 +819,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
         const int pstride = na.pal_stride;  // doubles per palette (layout.hpp)
         const int ubase = na.pal_ubase;
         double *sp = s_pal + wib * (kWave * pstride);
-        {   // the palettes of this tile's surfaces: G * pstride contiguous doubles -> LDS
-            const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * pstride);
-            double2 *sp2 = reinterpret_cast<double2 *>(sp);
-            const int n2 = G * (pstride / 2);
-            // (six loads in flight, then six LDS writes: a load-wait-write loop costs a memory round trip per pass)
-            for (int i0 = 0; i0 < n2; i0 += 6 * kWave) {
-                double2 t6[6];
-#pragma unroll
-                for (int q = 0; q < 6; q++) t6[q] = gp[min(i0 + q * kWave + lane, n2 - 1)];
-#pragma unroll
-                for (int q = 0; q < 6; q++)
-                    if (i0 + q * kWave + lane < n2) sp2[i0 + q * kWave + lane] = t6[q];
-            }
-        }
-        {
+        auto load_cls_T = [&]() {
             const unsigned char *pc = na.cls + tile.node_base + (int64_t)ll * M;
             if constexpr (M == 4) {
                 cw[0] = *reinterpret_cast<const unsigned int *>(pc);
@@ -799,13 +831,42 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
                     cw[2 * q + 1] = w0.y;
                 }
             }
-        }
-        const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
+            const double2 *pT = reinterpret_cast<const double2 *>(na.T + tile.node_base);
 #pragma unroll
-        for (int jp = 0; jp < M / 2; jp++) {
-            const double2 t = pT[jp * Lk + ll];
-            T[2 * jp] = t.x; T[2 * jp + 1] = t.y;
+            for (int jp = 0; jp < M / 2; jp++) {
+                const double2 t = pT[jp * Lk + ll];
+                T[2 * jp] = t.x; T[2 * jp + 1] = t.y;
+            }
+        };
+        // FUSED: the whole of a workgroup's start in flight at once — class bytes and T first, the palette pieces pinned
+        // where they are issued (the compiler sinks each load under the guard of its LDS write: six load-wait-write
+        // round trips), the zone data behind them. A resident workgroup starts into an idle memory system, its start is
+        // pure latency (13 000 of its 150 000 ticks at 20 sub-timesteps per call before this, 10 000 after). NOT for the
+        // streamed kernels: their tiles wait in a saturated memory pipeline, and the same order cost them registers for
+        // nothing (profiles/experiments/r03_all_tile_loads_in_flight.patch).
+        if constexpr (FUSED) {
+            load_cls_T();
+            fused_pre_b(blk, fa, pre);
         }
+        {   // the palettes of this tile's surfaces: G * pstride contiguous doubles -> LDS
+            const double2 *gp = reinterpret_cast<const double2 *>(na.pal + (int64_t)tile.surf_base * pstride);
+            double2 *sp2 = reinterpret_cast<double2 *>(sp);
+            const int n2 = G * (pstride / 2);
+            // (six loads in flight, then six LDS writes: a load-wait-write loop costs a memory round trip per pass)
+            for (int i0 = 0; i0 < n2; i0 += 6 * kWave) {
+                double2 t6[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) t6[q] = gp[min(i0 + q * kWave + lane, n2 - 1)];
+                if constexpr (FUSED) {
+                    asm volatile("" : "+v"(t6[0].x), "+v"(t6[1].x), "+v"(t6[2].x), "+v"(t6[3].x), "+v"(t6[4].x), "+v"(t6[5].x),
+                                      "+v"(pre.zT), "+v"(pre.za0), "+v"(pre.zb0), "+v"(pre.zvol), "+v"(pre.slot0));
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (i0 + q * kWave + lane < n2) sp2[i0 + q * kWave + lane] = t6[q];
+            }
+        }
+        if constexpr (!FUSED) load_cls_T();
         __builtin_amdgcn_wave_barrier();  // LDS writes above are ordered before the reads below (same wave)
         {
             const double *mp = sp + g * pstride;
@@ -835,7 +896,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
         }
     }
-    if constexpr (FUSED) fused_block_init(blk, fa, fl, blk_waves * kWave);  // the block's zone data -> LDS
+    if constexpr (FUSED) fused_block_init(blk, fa, fl, blk_waves * kWave, pre);  // the block's zone data -> LDS
 
     const int first_lane = lane - seg;
     const int nn = kind_n_mine >> 16;
