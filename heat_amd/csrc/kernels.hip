@@ -867,6 +867,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             }
         }
         if constexpr (!FUSED) load_cls_T();
+        HEAT_STAMP(6, false);
         __builtin_amdgcn_wave_barrier();  // LDS writes above are ordered before the reads below (same wave)
         {
             const double *mp = sp + g * pstride;
@@ -896,6 +897,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             U[2 * jp] = u.x; U[2 * jp + 1] = u.y;
         }
     }
+    HEAT_STAMP(7, false);
     if constexpr (FUSED) fused_block_init(blk, fa, fl, blk_waves * kWave, pre);  // the block's zone data -> LDS
 
     const int first_lane = lane - seg;

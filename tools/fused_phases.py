@@ -37,6 +37,10 @@ with HeatBatch(md, use_graph=True) as b:
           % (cfg, P, len(s), us * P, us))
     print("in-kernel clock: median %.3f GHz (p10 %.3f, p90 %.3f)" % (np.median(clk) / 1e9, np.percentile(clk, 10) / 1e9, np.percentile(clk, 90) / 1e9))
     whole = s[:, 3] - s[:, 0]
+    if (s[:, 6] > s[:, 0]).all() and (s[:, 7] >= s[:, 6]).all() and (s[:, 1] >= s[:, 7]).all():
+        for name, a, e in (("  init: loads arrived", 0, 6), ("  init: palettes decoded", 6, 7), ("  init: zone data, barrier", 7, 1)):
+            x = s[:, e] - s[:, a]
+            print("%-28s median %9.0f ticks" % (name, np.median(x)))
     for name, a, e in (("init", 0, 1), ("sub-timesteps", 1, 2), ("write-back", 2, 3), ("whole", 0, 3)):
         x = s[:, e] - s[:, a]
         print("%-14s median %9.0f ticks = %6.2f us (%5.1f %% of the workgroup's life)%s" % (
