@@ -59,7 +59,7 @@ __device__ __forceinline__ long long side_entry_pos(const SideConst &c) { return
 __device__ __forceinline__ void put_zone_contrib(const SideArrays &sd, const SideConst &c, double hs, double t_face) {
     if ((c.kind_n & 3) == KIND_SPACE) {
         ZoneContrib z;
-        z.hs = hs;
+        z.ha = hs * c.forced;  // (a Space-facing side's `forced` slot holds the area, layout.hpp)
         z.t_face = t_face;
         sd.zc[side_entry_pos(c)] = z;
     }
@@ -1300,7 +1300,7 @@ __device__ __forceinline__ void fast_tile_march(const FastTile tile, int counter
             // this side's share of its zone's heat balance (its place in the zone's list: from LDS, see above)
             if (active && (is_first || is_last) && (kind_n_mine & 3) == KIND_SPACE) {
                 ZoneContrib z;
-                z.hs = hs;
+                z.ha = hs * c.forced;  // (the area: layout.hpp, SideConst::forced of a Space-facing side)
                 z.t_face = face_t;
                 sd.zc[__double_as_longlong(s_pos[threadIdx.x])] = z;
             }
@@ -1844,6 +1844,7 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
     }
     if (z >= n_zones) return;
     double a = 0.0, b = 0.0;
+    (void)entries;
     const int64_t e0 = zone_off[z], e1 = zone_off[z + 1];
     // the zone's own terms are fetched beside the first entries (their latency is then off the serial tail)
     const double za0 = a0[z], zb0 = b0[z], tc = zone_T[z], zv = zone_vol[z];
@@ -1853,13 +1854,11 @@ k_zones(const int64_t *__restrict__ zone_off, const ZoneEntry *__restrict__ entr
         const bool two = e + kW < e1;
         const int64_t e2 = two ? e + kW : e;
         const ZoneContrib c0 = zc[e], c1 = zc[e2];
-        const double ha0 = c0.hs * entries[e].area;
-        a += ha0 * c0.t_face;
-        b += ha0;
+        a += c0.ha * c0.t_face;
+        b += c0.ha;
         if (two) {
-            const double ha1 = c1.hs * entries[e2].area;
-            a += ha1 * c1.t_face;
-            b += ha1;
+            a += c1.ha * c1.t_face;
+            b += c1.ha;
         }
     }
     if constexpr (ROWS) {

@@ -79,7 +79,8 @@ struct alignas(16) SideConst {
     double cos_eff;   // general / small classes: cos_surface_tilt as this side's ConvectionParams takes it (front
                       // Outdoor: -cos). FAST classes: the coefficient for air WARMER than the surface. Both are
                       // 1.31, 9.482 / (7.238 - |cos|) or 1.81 / (1.382 + |cos|) by the branches of convection.rs:87-110.
-    double forced;    // 2.537 * 1.67 * sqrt(perimeter * wind_modifier / area)  (src/convection.rs:157-163)
+    double forced;    // kind == KIND_OUTDOOR: 2.537 * 1.67 * sqrt(perimeter * wind_modifier / area)  (src/convection.rs:157-163);
+                      // kind == KIND_SPACE: the surface's area (model.rs:562-585: what the side's coefficient is weighted with)
     double nx, ny;    // surface normal (for is_windward)
 };
 // Inputs other modules write between marches, converted once at upload.
@@ -94,10 +95,11 @@ struct alignas(16) SideOut {
     double flow;      // convective heat flow
 };
 
-// A zone-facing side's share of calculate_zones_abc (model.rs:562-585): the new convection coefficient and the new
-// face temperature; k_zones multiplies by the area of the entry.
+// A zone-facing side's share of calculate_zones_abc (model.rs:562-585): the new convection coefficient times the surface's
+// area (a Space-facing side carries its area in SideConst::forced) and the new face temperature — k_zones sums these 16
+// bytes per entry and reads nothing else.
 struct alignas(16) ZoneContrib {
-    double hs;
+    double ha;
     double t_face;
 };
 
@@ -238,7 +240,8 @@ struct ZoneEntry {
     uint32_t hs_index;  // side record index (side * S + d) into SideArrays::out
     double area;
 };
-// (k_zones reads `area` only: the coefficient and the face temperature of entry e come from SideArrays::zc[e],
-// which the surface kernels fill — contiguous per zone instead of two gathers per entry.)
+// (k_zones reads none of it: coefficient x area and face temperature of entry e come from SideArrays::zc[e], which the
+// surface kernels fill — contiguous per zone instead of two gathers per entry. The entries stay as the host's record of
+// who contributes where.)
 
 }  // namespace heat

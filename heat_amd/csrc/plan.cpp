@@ -947,7 +947,8 @@ int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, 
                 c.cos_eff = pos;
                 c.alpha = neg;
             }
-            c.forced = kind == HEAT_BOUNDARY_OUTDOOR ? forced : 0.0;
+            // (a Space-facing side carries the surface's area here: what its contribution to the zone is weighted with)
+            c.forced = kind == HEAT_BOUNDARY_OUTDOOR ? forced : (kind == HEAT_BOUNDARY_SPACE ? d->area[s] : 0.0);
             if (side == 1 && kind == HEAT_BOUNDARY_AMBIENT) {
                 // A back side facing an ambient temperature takes t_front for its radiant temperature
                 // (surface.rs:672-686): the FRONT side's boundary source travels in this record's unused slots, so that
