@@ -224,6 +224,23 @@ def rocprof_kernel_us(counters_src, kernel_substr):
     return tot or None
 
 
+SETTLE_NOTE = ("untimed march calls of the same workload before the W warmup steps: the chip takes 20-30 ms of load to reach "
+               "the clock it then holds (tools/settle.py: 69.8 -> 64.4 us per sub-timestep of the headline over the first 25 ms; "
+               "back to 71 after two idle seconds) — without them a short timed region measures the ramp, not the kernel")
+
+
+def settle(march, weather, sync, ms, n_calls=None):
+    """The settle phase: march `weather` (one call) again and again for `ms` milliseconds, or exactly n_calls times
+    (N > 1: every rank the same count, agreed by the caller). Returns (calls, seconds)."""
+    t0 = time.perf_counter()
+    n = 0
+    while (n < n_calls) if n_calls is not None else ((time.perf_counter() - t0) * 1e3 < ms):
+        march(weather)
+        sync()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
 def march_in_calls(march, weather, per_call):
     """K sub-timesteps as march calls of `per_call` sub-timesteps (ThermalModel::march = one call)."""
     for i in range(0, len(weather), per_call):
@@ -340,6 +357,8 @@ def streaming_leg(md, state, args, config, dt, steps=60, warmup=10):
     from heat_amd import HeatBatch, modeldict as mdl
     with HeatBatch(md, nodes_per_lane=args.nodes_per_lane, no_palette=args.no_palette, no_fusion=True) as b:
         b.upload_state(state)
+        if args.settle_ms > 0:
+            settle(b.march_resident, mdl.weather_series(20, dt), b.synchronize, args.settle_ms)
         b.march_resident(mdl.weather_series(warmup, dt))
         b.synchronize()
         b.set_timing(True)
@@ -384,10 +403,11 @@ def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
         torch_sync = torch_device_sync(local_rank)
 
         def barrier():
+            batch.synchronize()  # the batch's own streams; reports device-side numerical flags
             if torch_sync:
                 torch_sync()
-            batch.synchronize()  # the batch's own streams; reports device-side numerical flags
 
+        settle_calls, settle_s = settle(batch.march_resident, mdl.weather_series(P, dt), barrier, args.settle_ms) if args.settle_ms > 0 else (0, 0.0)
         if W > 0:
             march_in_calls(batch.march_resident, mdl.weather_series(W, dt), P)
         barrier()
@@ -395,7 +415,7 @@ def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
         # launch); of a streamed march ONE call in three, or the first call only when the region has fewer (three events
         # per sub-timestep, issued eagerly — the other calls replay the hipGraph as an untimed march does)
         n_local = batch.n_surfaces_in_batch
-        fused = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if n_local <= 8192 else 3)
+        fused = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if n_local <= 8192 else 2)
         batch.set_timing(0 if args.no_timing else (1 if fused else max(3, -(-K // P))))
         weather_k = mdl.weather_series(K, dt, t0=dt * W)
         t0 = time.perf_counter()
@@ -409,6 +429,7 @@ def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
         n_fused = batch.n_fused_surfaces if not args.no_fusion else 0
         res = {"value": n_nodes * K / elapsed, "unit": "node-updates/s", "steps": K, "warmup": W,
                "ms_per_step": elapsed / K * 1e3, "sub_timesteps_per_sec": K / elapsed,
+               "settle": {"sub_timesteps": settle_calls * P, "ms": settle_s * 1e3, "note": SETTLE_NOTE},
                "config": {"workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
                           "config": config, "surfaces": int(md["n_surfaces"]), "nodes": n_nodes,
                           "zones": int(md["n_zones"]), "dt_s": dt, "substeps_per_march": P,
@@ -449,9 +470,11 @@ def single_gpu_leg(config, args, K, W, P, seed, local_rank, main, cpu_seconds):
                         "asks for every call; node temperatures on demand"}
             # how the sub-timesteps per march call change the picture (the reference's config 1 runs 2 per call)
             sens = {}
-            for p in (2, 5, 20):
+            if args.settle_ms > 0:  # (the copies above left the chip idle)
+                settle(batch.march_resident, mdl.weather_series(P, dt), batch.synchronize, args.settle_ms)
+            for p in (2, 4, 5, 20):
                 wv = mdl.weather_series(p, dt)
-                calls = max(2, 40 // p)
+                calls = max(4, 80 // p)
                 batch.march_resident(wv)
                 batch.synchronize()
                 t0 = time.perf_counter()
@@ -504,11 +527,20 @@ def sharded_leg(config, args, K, W, P, seed, rank, world, local_rank, weak):
             torch.cuda.synchronize()
             batch.synchronize()  # reports device-side numerical flags
 
+        settle_calls, settle_s = 0, 0.0
+        if args.settle_ms > 0:
+            # (every rank the same number of calls: the marches may hold a collective)
+            _, t1 = settle(sm.march_resident, mdl.weather_series(P, dt), barrier, 0.0, n_calls=1)
+            tt = torch.tensor([t1], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            n_calls = int(min(2000, max(1, args.settle_ms * 1e-3 / max(float(tt.item()), 1e-6))))
+            settle_calls, settle_s = settle(sm.march_resident, mdl.weather_series(P, dt), barrier, 0.0, n_calls=n_calls)
+            settle_calls += 1
         if W > 0:
             march_in_calls(sm.march_resident, mdl.weather_series(W, dt), P)
         barrier()
         n_local = batch.n_surfaces_in_batch
-        fused = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if n_local <= 8192 else 3)
+        fused = (not args.no_fusion) and batch.n_fused_surfaces > 0 and P >= (1 if n_local <= 8192 else 2)
         batch.set_timing(0 if args.no_timing else (1 if fused else max(3, -(-K // P))))
         t0 = time.perf_counter()
         march_in_calls(sm.march_resident, mdl.weather_series(K, dt, t0=dt * W), P)
@@ -525,6 +557,7 @@ def sharded_leg(config, args, K, W, P, seed, rank, world, local_rank, weak):
                "torch": "torch.distributed.all_gather_into_tensor", "none": "no collective issued"}[sm.collective]
         res = {"value": total_nodes * K / elapsed, "unit": "node-updates/s", "steps": K, "warmup": W,
                "ms_per_step": elapsed / K * 1e3, "sub_timesteps_per_sec": K / elapsed,
+               "settle": {"sub_timesteps": settle_calls * P, "ms": settle_s * 1e3, "note": SETTLE_NOTE},
                "n_shared_zones": n_shared, "collective": sm.collective, "comm_ranks": sm.comm_ranks,
                "collective_fallback": sm.collective_fallback,
                "config": {"workload": workload + "; one step = one sub-timestep (iterate_surfaces + zone update)",
@@ -574,6 +607,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the caller-owned-state and sub-timesteps-per-call measurements")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events in the timed region")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed march calls before the warmup steps, this long, so that the timed region runs at the "
+                         "clock the chip holds under load (0: none)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive the multi-GPU code path (ShardedMarch + zone exchange) even with one rank")
     ap.add_argument("--force-shared-zones", type=int, default=0,

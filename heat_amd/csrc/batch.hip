@@ -268,6 +268,7 @@ struct heat_batch {
     DevBuf<double> d_state;
     DevBuf<StepWeather> d_weather;
     DevBuf<int> d_step, d_flags;
+    int *h_flags = nullptr;  // pinned: the flags as of the last heat_batch_synchronize
     DevBuf<unsigned long long> d_nomass_iters;
 
     StepWeather *h_weather = nullptr;  // pinned
@@ -335,6 +336,7 @@ struct heat_batch {
         for (auto e : ev_copy) if (e) (void)hipEventDestroy(e);
         if (h_weather) (void)hipHostFree(h_weather);
         if (h_zone_ab) (void)hipHostFree(h_zone_ab);
+        if (h_flags) (void)hipHostFree(h_flags);
         for (int i = 0; i < kSideStreams; i++) {
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
             if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -1788,9 +1790,12 @@ int heat_batch_synchronize(heat_batch *b) {
     if (!b) return fail(HEAT_E_INVALID_ARG, "NULL batch");
     int rc = select_device(b);
     if (rc) return rc;
+    // The failure flags travel to pinned memory at the end of the stream's work, so that ONE wait covers march and flags
+    // (a synchronous copy behind the stream's wait is a second round trip to the device: 10-20 us of every short call).
+    if (!b->h_flags) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flags), 4 * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(b->h_flags, b->d_flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    int f[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(f, b->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    int f[4] = {b->h_flags[0], b->h_flags[1], b->h_flags[2], b->h_flags[3]};
     if (f[0]) {
         unsigned long long where;
         memcpy(&where, f + 2, sizeof where);
