@@ -529,13 +529,19 @@ def sharded_leg(config, args, K, W, P, seed, rank, world, local_rank, weak):
 
         settle_calls, settle_s = 0, 0.0
         if args.settle_ms > 0:
-            # (every rank the same number of calls: the marches may hold a collective)
-            _, t1 = settle(sm.march_resident, mdl.weather_series(P, dt), barrier, 0.0, n_calls=1)
-            tt = torch.tensor([t1], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            n_calls = int(min(2000, max(1, args.settle_ms * 1e-3 / max(float(tt.item()), 1e-6))))
-            settle_calls, settle_s = settle(sm.march_resident, mdl.weather_series(P, dt), barrier, 0.0, n_calls=n_calls)
-            settle_calls += 1
+            # (every rank the same number of calls — the marches may hold a collective —: blocks of calls whose length
+            # every rank derives from the same all-reduced time of the block before)
+            wsettle = mdl.weather_series(P, dt)
+            n_block = 1
+            while settle_s < args.settle_ms * 1e-3 and settle_calls < 4000:
+                _, t_block = settle(sm.march_resident, wsettle, barrier, 0.0, n_calls=n_block)
+                tt = torch.tensor([t_block], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_block = float(tt.item())
+                settle_s += t_block
+                settle_calls += n_block
+                left = args.settle_ms * 1e-3 - settle_s
+                n_block = int(min(500, max(1, left / max(t_block / n_block, 1e-6))))
         if W > 0:
             march_in_calls(sm.march_resident, mdl.weather_series(W, dt), P)
         barrier()
