@@ -131,7 +131,12 @@ struct DevBuf {
     hipError_t zeros(size_t count) {
         hipError_t e = alloc(count);
         if (e != hipSuccess || count == 0) return e;
-        return hipMemset(p, 0, count * sizeof(T));
+        // (the batch's streams do not wait for the null stream — hipStreamNonBlocking —: the fill must be over before
+        // any of them may touch the buffer. Found by tools/fuzz.py: the teams' exchange areas, allocated with the first team
+        // launch, were still being zeroed while the members published into them.)
+        e = hipMemset(p, 0, count * sizeof(T));
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(nullptr);
     }
 };
 
@@ -473,6 +478,7 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     HIP_TRY(b->d_step.zeros(2));  // [0] sub-timestep of the running march call, [1] its last one
     HIP_TRY(b->d_flags.zeros(4));  // [0] kinds OR-ed, [2..3] first failing surface / zone (report_failure, kernels.hip)
     HIP_TRY(hipMemset(b->d_flags.p + 2, 0xff, 2 * sizeof(int)));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     b->h_orig_of = p.orig_of;
     HIP_TRY(b->d_nomass_iters.zeros(p.n_nm_counters));
     if (Z > 0) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_zone_ab), 2 * Z * sizeof(double)));
@@ -914,7 +920,8 @@ int enqueue_fused(heat_batch *b, int n_sub, hipStream_t st, bool streamed_beside
         // what the chip holds of this variant, less a margin (the hardware may admit a workgroup per compute unit fewer than
         // the occupancy arithmetic says); other kernels in flight only delay a member's start, they end by themselves
         // (at most two per compute unit whatever the query says: the variants hold 171-256 registers)
-        const int room = n_cu * std::min(2, fused_team_blocks_per_cu(kFastM[c], kFastNM[c], b->na.pal_stride));
+        static const int team_room_env = getenv("HEAT_AMD_TEAM_ROOM") ? atoi(getenv("HEAT_AMD_TEAM_ROOM")) : 0;  // measurement
+        const int room = team_room_env > 0 ? team_room_env : n_cu * std::min(2, fused_team_blocks_per_cu(kFastM[c], kFastNM[c], b->na.pal_stride));
         int team_size = 2;
         for (const FusedSuper &su : b->h_team_supers[c]) team_size = std::max(team_size, (int)su.n_members);
         const int n_teams = std::min(n_super, std::max(0, room - room / 8) / team_size);
@@ -1801,6 +1808,7 @@ int heat_batch_synchronize(heat_batch *b) {
         memcpy(&where, f + 2, sizeof where);
         HIP_TRY(hipMemset(b->d_flags.p, 0, 2 * sizeof(int)));
         HIP_TRY(hipMemset(b->d_flags.p + 2, 0xff, 2 * sizeof(int)));
+        HIP_TRY(hipStreamSynchronize(nullptr));  // (the batch's streams do not wait for the null stream)
         // the first place (smallest number) and the kind that was seen there
         const int kinds = (int)(where & 0xff);
         const int64_t idx = (int64_t)(where >> 8);

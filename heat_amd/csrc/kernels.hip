@@ -431,6 +431,7 @@ k_surfaces_small(const GeneralTile *__restrict__ tiles, int n_tiles, NodeArrays 
 struct FusedLds {
     double2 *hT;            // (hs * area, face temperature) of the zone-facing sides, in the order of the zones' lists
     double *zT, *za0, *zb0, *zvol;
+    double *zsa, *zsb;      // teams: a member's own sums of a zone, between the pass that publishes them and the pass that gathers
     int *zoff;
     unsigned short *slots;  // place in hT of side [2][lanes] (front sides, then back sides, by lane of the workgroup)
 };
@@ -521,48 +522,57 @@ template <int TEAM>
 __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const FusedArgs &fa, const FusedLds &l, int wib,
                                                  int n_waves, int lane, int &bad_all, const TeamCtx &tc_) {
     __syncthreads();
-    auto finish = [&](int j, double a, double b, double tc, double cz) {
-        if constexpr (TEAM) {
-            const unsigned int info = fa.team_zinfo[blk.first_zone + j];
-            const unsigned int slot = info & 0xffffu, mask = info >> 16;
-            const unsigned int tag = fa.tag_base | ((unsigned int)tc_.round << 12) | (unsigned int)(tc_.it + 1);
-            unsigned long long *area = fa.xbuf + ((((size_t)tc_.team * 2 + (tc_.it & 1)) * kTeamZones + slot) * kTeamMax) * 4;
-            {   // publish this member's partial sums: four granules, one write-through store each
-                unsigned long long *g = area + tc_.member * 4;
-                const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
-                __hip_atomic_store(g + 0, team_granule((unsigned int)ab, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 1, team_granule((unsigned int)(ab >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 2, team_granule((unsigned int)bb, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 3, team_granule((unsigned int)(bb >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            double sa = 0.0, sb = 0.0;
-            for (int m = 0; m < kTeamMax; m++) {
-                if (!((mask >> m) & 1u)) continue;
-                double am = a, bm = b;
-                if (m != tc_.member) {
-                    const unsigned long long *g = area + m * 4;
-                    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-                    bool got = false;
-                    for (int spin = 0; spin < (1 << 21); spin++) {  // (~1 us per poll under load: seconds before giving up)
-                        g0 = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        g1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        g2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        g3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        got = (unsigned int)(g0 >> 32) == tag && (unsigned int)(g1 >> 32) == tag &&
-                              (unsigned int)(g2 >> 32) == tag && (unsigned int)(g3 >> 32) == tag;
-                        if (got) break;
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                    if (!got) atomicOr(tc_.flags, FLAG_EXCHANGE);  // (the member never came: reported, not waited for)
-                    am = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
-                    bm = __longlong_as_double((long long)((g2 & 0xffffffffull) | (g3 << 32)));
+    // TEAM: a zone faced from several members is balanced from all their sums. Every member PUBLISHES its sums of ALL its
+    // zones before it waits for anybody's (two passes below): a member that waited zone by zone could wait for a sum its
+    // partner publishes only after a zone it is itself still to reach — two members that share two zones and meet them in
+    // different orders would wait for each other for ever (found by tools/fuzz.py: members of more than 4 x wavefronts zones).
+    auto team_area = [&](int j, unsigned int &mask, unsigned int &tag) -> unsigned long long * {
+        const unsigned int info = fa.team_zinfo[blk.first_zone + j];
+        mask = info >> 16;
+        tag = fa.tag_base | ((unsigned int)tc_.round << 12) | (unsigned int)(tc_.it + 1);
+        return fa.xbuf + ((((size_t)tc_.team * 2 + (tc_.it & 1)) * kTeamZones + (info & 0xffffu)) * kTeamMax) * 4;
+    };
+    auto publish = [&](int j, double a, double b) {  // this member's partial sums: four granules, one write-through store each
+        unsigned int mask, tag;
+        unsigned long long *g = team_area(j, mask, tag) + tc_.member * 4;
+        const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+        __hip_atomic_store(g + 0, team_granule((unsigned int)ab, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, team_granule((unsigned int)(ab >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 2, team_granule((unsigned int)bb, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 3, team_granule((unsigned int)(bb >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto gather = [&](int j, double &a, double &b) {  // the sums of every member that faces the zone, added in member order
+        unsigned int mask, tag;
+        const unsigned long long *area = team_area(j, mask, tag);
+        double sa = 0.0, sb = 0.0;
+        for (int m = 0; m < kTeamMax; m++) {
+            if (!((mask >> m) & 1u)) continue;
+            double am = a, bm = b;
+            if (m != tc_.member) {
+                const unsigned long long *g = area + m * 4;
+                unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+                bool got = false;
+                for (int spin = 0; spin < (1 << 21); spin++) {  // (~1 us per poll under load: seconds before giving up)
+                    g0 = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    got = (unsigned int)(g0 >> 32) == tag && (unsigned int)(g1 >> 32) == tag &&
+                          (unsigned int)(g2 >> 32) == tag && (unsigned int)(g3 >> 32) == tag;
+                    if (got) break;
+                    __builtin_amdgcn_s_sleep(4);
                 }
-                sa += am;
-                sb += bm;
+                if (!got) atomicOr(tc_.flags, FLAG_EXCHANGE);  // (the member never came: reported, not waited for)
+                am = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
+                bm = __longlong_as_double((long long)((g2 & 0xffffffffull) | (g3 << 32)));
             }
-            a = sa;
-            b = sb;
+            sa += am;
+            sb += bm;
         }
+        a = sa;
+        b = sb;
+    };
+    auto finish = [&](int j, double a, double b, double tc, double cz) {
         a += l.za0[j];
         b += l.zb0[j];
         double ft = tc;
@@ -585,7 +595,13 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
             }
             a = wave_sum_f64(a);
             b = wave_sum_f64(b);
-            if (lane == 0) finish(j, a, b, tc, cz);
+            if (lane == 0) {
+                if constexpr (TEAM) {  // (one zone per wavefront: nothing of this member's is published behind this wait)
+                    publish(j, a, b);
+                    gather(j, a, b);
+                }
+                finish(j, a, b, tc, cz);
+            }
         }
     } else {
         const int row = lane >> 4, rl = lane & 15;
@@ -607,7 +623,28 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
             }
             a = row_sum_f64(a);
             b = row_sum_f64(b);
-            if (on && rl == 15) finish(j, a, b, tc, cz);
+            if constexpr (TEAM) {
+                if (on && rl == 15) {  // pass 1: publish, keep the own sums for pass 2 (same lane: no barrier needed)
+                    publish(j, a, b);
+                    l.zsa[j] = a;
+                    l.zsb[j] = b;
+                }
+            } else {
+                if (on && rl == 15) finish(j, a, b, tc, cz);
+            }
+        }
+        if constexpr (TEAM) {
+#pragma clang loop unroll(disable)
+            for (int j0 = 0; j0 < blk.n_zones; j0 += 4 * n_waves) {  // pass 2: everything of this member is published
+                const int j = j0 + 4 * wib + row;
+                if (j < blk.n_zones && rl == 15) {
+                    const double tc = l.zT[j];
+                    const double cz = zone_mcp(l.zvol[j], tc);
+                    double a = l.zsa[j], b = l.zsb[j];
+                    gather(j, a, b);
+                    finish(j, a, b, tc, cz);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1420,7 +1457,9 @@ k_surfaces_fast(const FastTile *__restrict__ tiles, int n_tiles, NodeArrays na, 
     fl.za0 = fl.zT + kFusedMaxZones;
     fl.zb0 = fl.za0 + kFusedMaxZones;
     fl.zvol = fl.zb0 + kFusedMaxZones;
-    fl.zoff = reinterpret_cast<int *>(fl.zvol + kFusedMaxZones);
+    fl.zsa = fl.zvol + kFusedMaxZones;
+    fl.zsb = fl.zsa + kFusedMaxZones;
+    fl.zoff = reinterpret_cast<int *>(fl.zsb + kFusedMaxZones);
     fl.slots = reinterpret_cast<unsigned short *>(fl.zoff + kFusedMaxZones + 2);
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x >> 6;
@@ -2184,7 +2223,7 @@ void launch_surfaces_stream(int variant, const FastTile *tiles, int n_tiles, con
 // sub-timesteps in one launch. Palette classes without cavities only.
 size_t fused_lds_bytes(int max_waves, int M, int pal_stride) {
     return (size_t)max_waves * kWave * ((pal_stride + (M == 16 ? M : 0)) * sizeof(double) + 2 * sizeof(double2)) +
-           4 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
+           6 * kFusedMaxZones * sizeof(double) + (kFusedMaxZones + 2) * sizeof(int) + kFusedMaxEntries * sizeof(uint16_t);
 }
 
 template <int MM, int NN, int CC, int FW, int SM>

@@ -5,6 +5,7 @@ reference CPU path. Every comparison below uses rtol = 1e-9 with atol = 1e-9 (te
 Celsius and cross zero, heat flows reach zero at equilibrium).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -447,6 +448,20 @@ def test_teams_beside_short_calls_and_zone_lists_rebuilt(oracle):
         with pytest.raises(HeatError):
             b.set_shared_zones(np.array([5], dtype=np.int32))
     assert_state_close(md, ref, got)
+
+
+@pytest.mark.parametrize("seed", [10802, 10846, 10968, 11073])
+def test_cases_the_fuzzer_found(seed):
+    """tools/fuzz.py, round 3: buildings of seven-node walls (one lane per wall, 64 walls per wavefront) rewired into one
+    cluster — a team whose members hold more than sixteen zones each. A member that published and awaited its zones one
+    after the other could wait for a sum its partner publishes only behind a zone the partner is itself waiting at (the march
+    ended with HEAT_E_DEVICE after the bounded wait); members now publish everything before they wait for anything."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz
+    line = fuzz.run_case(seed)
+    assert line is not None and "fused" in line
+    print(line)
 
 
 @pytest.mark.parametrize("mode", ["planned", "streamed", "general"])
