@@ -1491,6 +1491,7 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
     rc = rebuild_unified(b);
     if (rc) return rc;
     if (b->graph_exec) {  // the captured sub-timestep graph holds the old tile counts
+        HIP_TRY(hipStreamSynchronize(b->stream));
         (void)hipGraphExecDestroy(b->graph_exec);
         b->graph_exec = nullptr;
     }
@@ -1760,6 +1761,8 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
         const int want = std::max(1, b->graph_recaptures > 8 ? 1 : (per_graph_env > 0 ? std::min(per_graph_env, n_sub) : std::min(n_sub, 32)));
         if (!b->graph_exec || b->graph_fused != fused || b->graph_subs <= 0 || (b->graph_subs != want && n_sub % b->graph_subs != 0)) {
             if (b->graph_exec && b->graph_fused == fused) b->graph_recaptures++;
+            // (a call of another length: the graph of the calls before may still be running — it goes only when it is done)
+            if (b->graph_exec) HIP_TRY(hipStreamSynchronize(b->stream));
             if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
             if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
             HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));

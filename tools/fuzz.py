@@ -7,7 +7,7 @@ Prints one line per case; a failing case prints its recipe (seed, options) and t
 Round 3: 4 400 cases in seven minutes found two faults of the teams of workgroups — the exchange areas still being zeroed on
 the null stream while the first team launch published into them, and members of more than sixteen zones waiting for each
 other's sums zone by zone — both fixed, their seeds kept as tests (tests/test_parity_gpu.py).""" 
-import os, sys, time, traceback
+import faulthandler, os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -105,7 +105,86 @@ def run_case(seed):
     return "%-40s S=%-6d Z=%-5d n_sub=%-2d calls %s %s | %s" % (name, int(md["n_surfaces"]), int(md["n_zones"]), len(w), cuts, kw, info)
 
 
+def run_sharded_case(seed):
+    """The same case cut into 2-8 shards that all live on this one device: heat_partition's cut (whole clusters per rank, an
+    oversized cluster cut through) or — every other time — arbitrary surface ranges (many zones shared), each shard a batch of
+    its own, the zones they share exchanged through the split-phase ABI (heat_batch_step_surfaces -> every rank's partial
+    (a, b) block -> heat_batch_step_zones, the blocks summed in rank order) with this process playing the collective."""
+    import torch
+    from heat_amd import binding
+    from heat_amd.sharded import zone_roles
+    md, st, name, w, a0, b0, kw, cuts = make_case(seed)
+    rng = np.random.default_rng(seed ^ 0x5eed)
+    S = int(md["n_surfaces"]); Z = int(md["n_zones"])
+    R = int(rng.choice([2, 3, 4, 8]))
+    if S < 2 * R:
+        return None
+    if rng.random() < 0.5:
+        ranks, _ = binding.partition(md, R)
+        how = "heat_partition"
+    else:
+        edges = np.sort(rng.choice(np.arange(1, S), R - 1, replace=False))
+        ranks = np.searchsorted(edges, np.arange(S), side="right").astype(np.int32)
+        how = "ranges"
+    if len(np.unique(ranks)) < R:
+        return None
+    ref = st.copy()
+    rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
+    if rc != 0:
+        return None
+    kw = {k: v for k, v in kw.items() if k != "use_graph"}
+    batches = [HeatBatch(md, n_ranks=R, rank=r, rank_of_surface=ranks, **kw) for r in range(R)]
+    try:
+        masks = [b.touched_zones() for b in batches]
+        cnt = np.sum(np.asarray(masks, dtype=np.int64), axis=0)
+        shared = None
+        for r, b in enumerate(batches):
+            shared, owned = zone_roles(cnt, masks[r], r, R)
+            b.set_owned_zones(owned)
+            b.set_shared_zones(shared)
+        n = max(2 * len(shared), 2)
+        gathered = torch.zeros(R * n, dtype=torch.float64, device="cuda")
+        for r, b in enumerate(batches):
+            b.use_partials(gathered.data_ptr() + r * n * 8)
+            b.upload_state(st)
+        lo = 0
+        for c in cuts:
+            if c <= lo:
+                continue
+            wv = w[lo:c]
+            for b in batches:
+                b.set_weather(wv, a0, b0)
+            for i in range(len(wv)):
+                for b in batches:
+                    b.step_surfaces(i)
+                torch.cuda.synchronize()
+                if len(shared):
+                    for b in batches:
+                        b.step_zones(gathered.data_ptr(), R)
+                    torch.cuda.synchronize()
+            lo = c
+        got = st.copy()
+        total = 0
+        for b in batches:
+            b.synchronize()
+            b.download_state(got)
+            total += b.nomass_iterations()
+        assert total == iters, ("no-mass passes", total, iters)
+        info = "fused %s" % [b.n_fused_surfaces for b in batches]
+    finally:
+        for b in batches:
+            b.close()
+    assert_state_close(md, ref, got)
+    return "%-40s S=%-6d Z=%-5d n_sub=%-2d %d shards by %s, %d zones shared %s | %s" % (
+        name, S, Z, len(w), R, how, len(shared), kw, info)
+
+
 if __name__ == "__main__":
+    try:  # (torch carries the sharded cases' exchange buffer: it wants to see the device before anybody else holds it)
+        import torch
+        torch.cuda.is_available() and torch.zeros(1, device="cuda")
+    except Exception:  # noqa
+        pass
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
     only = [int(a) for a in sys.argv[3:]]          # given: exactly these seeds (a failing case again)
@@ -118,8 +197,10 @@ if __name__ == "__main__":
         if time.time() >= t_end:
             break
         last = seed
+        print("     seed %d ..." % seed, flush=True)          # (a case that hangs or crashes the process names itself)
+        faulthandler.dump_traceback_later(90, exit=True)       # ... and ends the run instead of the GPU box's patience
         try:
-            line = run_case(seed)
+            line = run_sharded_case(seed) if seed % 4 == 3 else run_case(seed)
             if line is not None:
                 n_ok += 1
                 print("ok   seed %d %s" % (seed, line), flush=True)
