@@ -215,6 +215,7 @@ struct heat_batch {
     // ... in three parts, one per variant of the kernel (kernels.hip: 16 nodes per lane | 8 / 4 nodes per lane and small
     // surfaces | tiles with no-mass chunks other than facings), launched back to back: [part] = first tile, tiles
     int ulist_part[2][kStreamVariants][2] = {};
+    bool capturing = false;         // a stream capture of the batch's stream is under way (enqueue_surfaces does not fork then)
     unsigned int sweep_parity = 0;  // enqueue_surfaces: direction of the next streamed sweep (zig-zag)
     unsigned int fused_parity = 0;  // enqueue_fused: direction of the next cluster-resident launch
     bool class_has_chunks[kNumFast] = {};  // the class holds tiles with such chunks: its own launch takes the NM = 2 variant
@@ -755,18 +756,25 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
     n_launch += n_cav_tiles > 0;
     n_launch += b->n_gen_tiles > b->n_small_tiles;
     static const bool no_fork = getenv("HEAT_AMD_NO_FORK") != nullptr;  // measurement: every class on the batch's stream
-    const bool fork = n_launch > 1 && b->side[0] != nullptr && !no_fork;
-    int used = 0, slot = 0;
+    // (not inside a stream capture: three of the fuzzer's cases — batches without palettes, whose two or three class launches
+    // were forked onto side streams inside the captured sub-timestep — ended in a hang or a crash of the process inside the
+    // HIP runtime at the SECOND capture of a batch (a march call of another length); captured, the launches follow each other
+    // on the batch's stream, where a graph leaves no gap between them anyway)
+    const bool fork = n_launch > 1 && b->side[0] != nullptr && !no_fork && !b->capturing;
+    // Exactly the side streams that get work are forked, and every forked one is joined below: inside a stream capture a
+    // side stream that waits for the fork event and is never joined leaves the capture unjoined — found by tools/fuzz.py
+    // as a hang or a crash of the process some captures later (batches without palettes: two or three class launches on
+    // three side streams).
+    const int n_side = fork ? std::min(n_launch - 1, (int)heat_batch::kSideStreams) : 0;
+    int slot = 0;
     auto next_stream = [&]() -> hipStream_t {
-        if (!fork) return b->stream;
-        const int s = slot++ % (heat_batch::kSideStreams + 1);
-        if (s == 0) return b->stream;
-        used |= 1 << (s - 1);
-        return b->side[s - 1];
+        if (n_side == 0) return b->stream;
+        const int s = slot++ % (n_side + 1);
+        return s == 0 ? b->stream : b->side[s - 1];
     };
-    if (fork) {
+    if (n_side > 0) {
         (void)hipEventRecord(b->ev_fork, b->stream);
-        for (int i = 0; i < heat_batch::kSideStreams; i++) (void)hipStreamWaitEvent(b->side[i], b->ev_fork, 0);
+        for (int i = 0; i < n_side; i++) (void)hipStreamWaitEvent(b->side[i], b->ev_fork, 0);
     }
     if (unified) {
         // the parts follow each other on ONE stream (a dependency between two streams costs more than the tail of a part)
@@ -818,12 +826,9 @@ void enqueue_surfaces(heat_batch *b, int step_fixed, bool streamed_only = false)
                                 b->gen_base, b->sa, b->d_cavs.p, b->d_scratch.p, b->d_weather.p, b->d_step.p,
                                 step_fixed, b->d_zone_T.p, b->d_flags.p, cnt + (size_t)b->n_small_tiles * kWave,
                                 next_stream());
-    if (fork) {
-        for (int i = 0; i < heat_batch::kSideStreams; i++) {
-            if (!(used & (1 << i))) continue;
-            (void)hipEventRecord(b->ev_join[i], b->side[i]);
-            (void)hipStreamWaitEvent(b->stream, b->ev_join[i], 0);
-        }
+    for (int i = 0; i < n_side; i++) {
+        (void)hipEventRecord(b->ev_join[i], b->side[i]);
+        (void)hipStreamWaitEvent(b->stream, b->ev_join[i], 0);
     }
 }
 
@@ -1766,10 +1771,12 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
             if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
             if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
             HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+            b->capturing = true;
             for (int i = 0; i < want; i++) {
                 enqueue_surfaces(b, -1, fused);
                 enqueue_zones(b, zmode);
             }
+            b->capturing = false;
             HIP_TRY(hipStreamEndCapture(b->stream, &b->graph));
             HIP_TRY(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
             b->graph_fused = fused;
