@@ -216,6 +216,7 @@ struct heat_batch {
     // surfaces | tiles with no-mass chunks other than facings), launched back to back: [part] = first tile, tiles
     int ulist_part[2][kStreamVariants][2] = {};
     bool capturing = false;         // a stream capture of the batch's stream is under way (enqueue_surfaces does not fork then)
+    bool host_zones_stale = false;  // the device has marched since the caller's state last received the zone temperatures
     unsigned int sweep_parity = 0;  // enqueue_surfaces: direction of the next streamed sweep (zig-zag)
     unsigned int fused_parity = 0;  // enqueue_fused: direction of the next cluster-resident launch
     bool class_has_chunks[kNumFast] = {};  // the class holds tiles with such chunks: its own launch takes the NM = 2 variant
@@ -1150,7 +1151,9 @@ static int transfer_in(heat_batch *b, const double *state, size_t n_state, bool 
 }
 
 int heat_batch_upload_state(heat_batch *b, const double *state, size_t n_state) {
-    return transfer_in(b, state, n_state, true);
+    const int rc = transfer_in(b, state, n_state, true);
+    if (rc == HEAT_OK) b->host_zones_stale = false;
+    return rc;
 }
 // Only what other modules write between two marches (surface_trait.rs:81-125's irradiance slots, the zones'
 // dry-bulb slots): gathered on the host into pinned memory, one copy, converted on the device.
@@ -1174,10 +1177,16 @@ int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state)
         if (e > a)
             HIP_TRY(hipMemcpyAsync(b->d_compact.p + a, pin + a, (size_t)(e - a) * sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
-    for (int64_t z = 0; z < Z; z++) pin[4 * S + z] = state[b->h_zone_slot_h[z]];
-    if (Z > 0)
+    // The zones' dry-bulb slots are taken from the caller's state only while that state holds what this path last
+    // computed: after a march whose outputs left HEAT_OUT_ZONE_TEMPERATURES out (heat_batch_march_ex, or a resident march
+    // without a download) the caller's zone slots are OLDER than the device's — taking them would set the zones back by a
+    // call (found by tools/fuzz.py). heat_batch_upload_state always takes everything.
+    const bool take_zones = Z > 0 && !b->host_zones_stale;
+    if (take_zones) {
+        for (int64_t z = 0; z < Z; z++) pin[4 * S + z] = state[b->h_zone_slot_h[z]];
         HIP_TRY(hipMemcpyAsync(b->d_compact.p + 4 * S, pin + 4 * S, (size_t)Z * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    launch_inputs_compact((int)S, (int)Z, b->d_compact.p, b->d_side_alpha.p, b->d_side_dyn.p, b->d_zone_T.p, b->sl,
+    }
+    launch_inputs_compact((int)S, take_zones ? (int)Z : 0, b->d_compact.p, b->d_side_alpha.p, b->d_side_dyn.p, b->d_zone_T.p, b->sl,
                           b->direct_runs.empty() ? nullptr : b->d_state.p, b->stream);
     HIP_TRY(hipGetLastError());
     return HEAT_OK;
@@ -1205,6 +1214,7 @@ static int download_impl(heat_batch *b, double *state, size_t n_state, int32_t w
     int rc = select_device(b);
     if (rc) return rc;
     const int64_t S = b->n_surf, Z = b->n_zones, N = b->n_nodes;
+    const bool delivers_zones = (what & HEAT_OUT_ZONE_TEMPERATURES) != 0;
     bool nodes = (what & HEAT_OUT_NODE_TEMPERATURES) != 0;
     bool scalars = (what & (HEAT_OUT_SURFACE_SCALARS | HEAT_OUT_ZONE_TEMPERATURES)) != 0;
     if (nodes && (what & HEAT_OUT_SURFACE_SCALARS) && inputs_fresh && !b->direct_runs.empty()) {
@@ -1288,6 +1298,7 @@ static int download_impl(heat_batch *b, double *state, size_t n_state, int32_t w
         }
         if (!overlap && i + 1 < pieces.size()) HIP_TRY(issue(i + 1));
     }
+    if (delivers_zones) b->host_zones_stale = false;  // (the caller's zone slots are the device's again)
     return HEAT_OK;
 }
 
@@ -1339,6 +1350,7 @@ int heat_batch_step_surfaces(heat_batch *b, int32_t sub_step) {
     if (sub_step < 0 || sub_step >= b->n_weather) return fail(HEAT_E_INVALID_ARG, "sub_step %d outside the weather set (%d)", sub_step, b->n_weather);
     int rc = select_device(b);
     if (rc) return rc;
+    b->host_zones_stale = true;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (b->timing) {
         e0 = next_event(b); e1 = next_event(b); e2 = next_event(b);
@@ -1646,6 +1658,7 @@ int heat_batch_march_resident(heat_batch *b, const heat_weather *weather, int32_
     // A march of no sub-timestep (model.rs:369: the loop body never runs) is the head kernel and nothing else: the
     // graph branch below must never capture or replay an empty graph.
     if (n_sub == 0) return HEAT_OK;
+    b->host_zones_stale = true;  // (until a download delivers the zones again)
     if (b->comm && exchange) {
         // Sharded sub-timestep, everything in order on the batch's stream (no cross-queue dependency anywhere):
         // this rank's surfaces -> zones only this rank touches finished, partial (a, b) of the shared zones ->

@@ -159,7 +159,9 @@ void heat_batch_destroy(heat_batch *b);
 int heat_batch_upload_state(heat_batch *b, const double *state, size_t n_state);
 int heat_batch_download_state(heat_batch *b, double *state, size_t n_state);
 /* Only what other modules write between two march calls: solar + IR irradiance slots
- * and zone dry-bulb temperatures. */
+ * and zone dry-bulb temperatures. The zone slots are taken only while `state` holds what this path last computed
+ * for them: after a march whose outputs left HEAT_OUT_ZONE_TEMPERATURES out (or a resident march without a download)
+ * the caller's zone slots are older than the device's and are NOT read — heat_batch_upload_state takes everything. */
 int heat_batch_upload_inputs(heat_batch *b, const double *state, size_t n_state);
 
 /*

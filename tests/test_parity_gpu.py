@@ -450,6 +450,20 @@ def test_teams_beside_short_calls_and_zone_lists_rebuilt(oracle):
     assert_state_close(md, ref, got)
 
 
+@pytest.mark.parametrize("seed", [60009, 60029, 60057])
+def test_drop_in_calls_with_output_masks_the_fuzzer_found(seed):
+    """tools/fuzz.py, round 3: heat_batch_march_ex on a caller-owned state, new irradiances between the calls, a random
+    output mask per call. A call that left HEAT_OUT_ZONE_TEMPERATURES out left the caller's zone slots a call behind the
+    device's — and the next call's upload of "what other modules write" took them and set the zones back (4e-2 K, other pass
+    counts). The zone slots are now read only while the caller's state holds what the path last computed for them."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz
+    line = fuzz.run_dropin_case(seed)
+    assert line is not None and "drop-in" in line
+    print(line)
+
+
 @pytest.mark.parametrize("seed", [10802, 10846, 10968, 11073])
 def test_cases_the_fuzzer_found(seed):
     """tools/fuzz.py, round 3: buildings of seven-node walls (one lane per wall, 64 walls per wavefront) rewired into one
