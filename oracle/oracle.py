@@ -268,9 +268,14 @@ def build_segments(layers, n_elements, height=1.0, angle=0.0, tstep_subdivision=
                 alpha_rc=rc)
 
 
+MAX_NODES = 1024  # OR_MAX_NODES of heat_oracle.c: its scratch arrays per surface
+
+
 def get_chunks(mass):
     mass = _arr(mass, np.float64)
     n = len(mass)
+    if n > MAX_NODES:
+        raise ValueError("the oracle holds %d nodes per surface at most (OR_MAX_NODES), got %d" % (MAX_NODES, n))
     nm, nn = C.c_int(0), C.c_int(0)
     mc = (C.c_int * (2 * n + 2))()
     nc = (C.c_int * (2 * n + 2))()

@@ -134,3 +134,13 @@ def test_model_builder_orders_fenestrations_last_and_picks_the_strictest_dt():
     sub = max(i["tstep_subdivision"] for i in infos)
     assert n_sub == 2 * sub and md["dt"] == 3600. / (6 * sub) / 2.
     mb.close()
+
+
+def test_random_constructions_equal_the_oracles():
+    """tools/fuzz_setup.py: random layer stacks (1-6 layers, gas gaps, glass, random timesteps) through the product's setup
+    library and the oracle's restatement, value for value — a short run of it (360 000 constructions equal in round 3)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_setup.py"), "4", "777"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " 0 differ" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+

@@ -1,0 +1,73 @@
+"""The product's setup-time library (heat_amd/csrc/setup.cpp: discretize_construction, build, get_chunks, the alpha
+distribution) against the oracle's independent restatement on random constructions, value for value. CPU only.
+    python tools/fuzz_setup.py [SECONDS] [FIRST_SEED]"""
+import os, sys, time, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from heat_amd import binding, modeldict as mdl
+from oracle import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+oracle.lib()
+t_end = time.time() + budget
+n = bad = rejected = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    nl = int(rng.integers(1, 7))
+    layers = []
+    for i in range(nl):
+        gas_ok = 0 < i < nl - 1 and not layers[-1].get("is_gas")
+        if gas_ok and rng.random() < 0.25:
+            layers.append(dict(thickness=float(rng.uniform(0.004, 0.08)), is_gas=True, gas=int(rng.choice([mdl.AIR, mdl.ARGON]))))
+            continue
+        L = dict(thickness=float(10 ** rng.uniform(-3, -0.3)), k=float(10 ** rng.uniform(-1.7, 0.5)),
+                 rho=float(10 ** rng.uniform(1, 3.5)), cp=float(rng.uniform(400., 2600.)))
+        if rng.random() < 0.5:
+            L.update(front_thermal_abs=float(rng.uniform(0, 1)), back_thermal_abs=float(rng.uniform(0, 1)),
+                     front_solar_abs=float(rng.uniform(0, 1)), back_solar_abs=float(rng.uniform(0, 1)))
+        if rng.random() < 0.1:
+            L.update(tau=float(rng.uniform(0.1, 0.9)), front_solar_abs=float(rng.uniform(0, 0.1)), back_solar_abs=float(rng.uniform(0, 0.1)))
+        layers.append(L)
+    main_dt = float(rng.choice([60., 90., 180., 300., 600., 900., 1800., 3600.]))
+    max_dx = float(rng.choice([0.04, 0.02, 0.1]))
+    min_dt = float(rng.choice([60., 30., 120.]))
+    angle = float(rng.uniform(0, math.pi))
+    ra = rb = None
+    try:
+        a = binding.discretize(layers, main_dt, max_dx, min_dt, 1., angle)
+    except Exception as e:  # noqa
+        ra = str(e)[:80]
+    try:
+        b = oracle.discretize(layers, main_dt, max_dx, min_dt, 1., angle)
+    except Exception as e:  # noqa
+        rb = str(e)[:80]
+    if ra or rb:
+        if bool(ra) != bool(rb):
+            bad += 1
+            print("FAIL seed %d: one side rejects: product %r oracle %r" % (seed, ra, rb), flush=True)
+        else:
+            rejected += 1
+        seed += 1
+        continue
+    # (a mixture of transparent and opaque layers: the reference panics, surface.rs:470-472,506-508 — both sides say so with
+    # a negative alpha_rc, the code itself is theirs; the alphas are then unspecified)
+    both_reject = a["alpha_rc"] < 0 and b["alpha_rc"] < 0
+    if both_reject:
+        rejected += 1
+    ok = a["tstep_subdivision"] == b["tstep_subdivision"] and a["n_elements"] == b["n_elements"] and (both_reject or a["alpha_rc"] == b["alpha_rc"])
+    for k in ("mass", "uvalue") + (() if both_reject else ("front_alpha", "back_alpha")):
+        ok = ok and np.array_equal(a[k], b[k], equal_nan=True)
+    ok = ok and np.array_equal(a["seg_cavity"], b["seg_cavity"])
+    for f in ("thickness", "height", "angle", "eout", "ein", "gas"):
+        ok = ok and np.array_equal(a["cavities"][f], b["cavities"][f])
+    if len(b["mass"]) <= oracle.MAX_NODES:  # (the oracle's scratch arrays hold 1 024 nodes per surface)
+        ok = ok and binding.get_chunks(a["mass"]) == oracle.get_chunks(b["mass"])
+    if not ok:
+        bad += 1
+        print("FAIL seed %d: %d layers main_dt %g: product and oracle differ (n_elements %s / %s, subdivision %s / %s)" % (
+            seed, nl, main_dt, a["n_elements"], b["n_elements"], a["tstep_subdivision"], b["tstep_subdivision"]), flush=True)
+    n += 1
+    seed += 1
+print("fuzz_setup: %d constructions equal, %d rejected by both, %d differ" % (n, rejected, bad))
+sys.exit(1 if bad else 0)
