@@ -567,6 +567,8 @@ int build(heat_batch *b, const heat_batch_desc *d, const heat_batch_options &opt
     const int64_t *sp = b->d_slots.p;
     sl.hs_f = sp; sl.hs_b = sp + S; sl.flow_f = sp + 2 * S; sl.flow_b = sp + 3 * S;
     sl.solar_f = sp + 4 * S; sl.solar_b = sp + 5 * S; sl.ir_f = sp + 6 * S; sl.ir_b = sp + 7 * S;
+    // (every upload and fill above went through the null stream; the batch's streams do not wait for it)
+    HIP_TRY(hipDeviceSynchronize());
     return HEAT_OK;
 }
 
@@ -1512,6 +1514,7 @@ int heat_batch_set_shared_zones(heat_batch *b, const int32_t *shared_zone, int32
         (void)hipGraphExecDestroy(b->graph_exec);
         b->graph_exec = nullptr;
     }
+    HIP_TRY(hipDeviceSynchronize());  // (the uploads above went through the null stream; the batch's streams do not wait for it)
     return HEAT_OK;
 }
 
