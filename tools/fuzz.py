@@ -57,7 +57,7 @@ def check(md, ref, got, gpu_iters, iters, oracle_again):
                         for k in ("hs_front_slot", "hs_back_slot", "flow_front_slot", "flow_back_slot"))
             if tight and loose:
                 raise IllConditioned(str(e)[:160])
-        for eps in (1e-15, -1e-15, 4e-15):
+        for eps in (1e-15, -1e-15, 3e-15, -4e-15):
             r2 = oracle_again(eps)
             jump = float(np.max(np.abs(r2[slots] - ref[slots])))
             if jump > 1e-9 * (1.0 + float(np.max(np.abs(ref[slots])))):
@@ -122,6 +122,9 @@ def make_case(seed):
     n_sub = int(rng.integers(1, 14))
     if huge:
         n_sub = min(n_sub, 4)
+    elif not big and np.random.default_rng(seed ^ 0x10a6).random() < 0.06:
+        # a long march (small models only): more sub-timesteps than one captured graph holds (32), blocks and a remainder
+        n_sub = int(np.random.default_rng(seed ^ 0x10a7).integers(33, 90))
     w = mdl.weather_series(n_sub, float(md["dt"]), wind_speed=float(rng.uniform(0.0, 8.0)), wind_deg=float(rng.uniform(0, 360)))
     a0 = rng.uniform(0., 50., Z)
     b0 = rng.uniform(0., 2., Z)
@@ -159,6 +162,7 @@ def run_case(seed):
         r2 = st.copy()
         for key in ("ir_front_slot", "ir_back_slot"):
             r2[md[key]] *= 1.0 + eps
+        r2[mdl.node_slots(md)] *= 1.0 + eps
         oracle.OracleModel(md).march(r2, w, a0, b0)
         return r2
     got = st.copy()
@@ -226,6 +230,7 @@ def run_dropin_case(seed):
 
     def oracle_again(eps):
         r2 = st.copy()
+        r2[mdl.node_slots(md)] *= 1.0 + eps
         o2 = oracle.OracleModel(md)
         for written, wv, a_c, b_c in script:
             for key, v in written.items():
@@ -301,12 +306,19 @@ def run_sharded_case(seed):
             b.synchronize()
             b.download_state(got)
             total += b.nomass_iterations()
-        assert total == iters, ("no-mass passes", total, iters)
         info = "fused %s" % [b.n_fused_surfaces for b in batches]
     finally:
         for b in batches:
             b.close()
-    assert_state_close(md, ref, got)
+
+    def oracle_again(eps):
+        r2 = st.copy()
+        for key in ("ir_front_slot", "ir_back_slot"):
+            r2[md[key]] *= 1.0 + eps
+        r2[mdl.node_slots(md)] *= 1.0 + eps
+        oracle.OracleModel(md).march(r2, w, a0, b0)
+        return r2
+    check(md, ref, got, total, iters, oracle_again)
     return "%-40s S=%-6d Z=%-5d n_sub=%-2d %d shards by %s, %d zones shared %s | %s" % (
         name, S, Z, len(w), R, how, len(shared), kw, info)
 
