@@ -605,6 +605,8 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
         }
     } else {
         const int row = lane >> 4, rl = lane & 15;
+        const bool one_pass = blk.n_zones <= 4 * n_waves;  // (workgroup-uniform) the loop below runs once
+        (void)one_pass;
 #pragma clang loop unroll(disable)
         for (int j0 = 0; j0 < blk.n_zones; j0 += 4 * n_waves) {  // (workgroup-uniform trip count)
             const int j = j0 + 4 * wib + row;
@@ -624,25 +626,32 @@ __device__ __forceinline__ void fused_zone_phase(const FusedBlock &blk, const Fu
             a = row_sum_f64(a);
             b = row_sum_f64(b);
             if constexpr (TEAM) {
-                if (on && rl == 15) {  // pass 1: publish, keep the own sums for pass 2 (same lane: no barrier needed)
+                if (on && rl == 15) {
                     publish(j, a, b);
-                    l.zsa[j] = a;
-                    l.zsb[j] = b;
+                    if (one_pass) {  // (a row meets one zone only: everything of this member is published before any wait)
+                        gather(j, a, b);
+                        finish(j, a, b, tc, cz);
+                    } else {  // pass 1: keep the own sums for pass 2 (same lane: no barrier needed)
+                        l.zsa[j] = a;
+                        l.zsb[j] = b;
+                    }
                 }
             } else {
                 if (on && rl == 15) finish(j, a, b, tc, cz);
             }
         }
         if constexpr (TEAM) {
+            if (!one_pass) {
 #pragma clang loop unroll(disable)
-            for (int j0 = 0; j0 < blk.n_zones; j0 += 4 * n_waves) {  // pass 2: everything of this member is published
-                const int j = j0 + 4 * wib + row;
-                if (j < blk.n_zones && rl == 15) {
-                    const double tc = l.zT[j];
-                    const double cz = zone_mcp(l.zvol[j], tc);
-                    double a = l.zsa[j], b = l.zsb[j];
-                    gather(j, a, b);
-                    finish(j, a, b, tc, cz);
+                for (int j0 = 0; j0 < blk.n_zones; j0 += 4 * n_waves) {  // pass 2: everything of this member is published
+                    const int j = j0 + 4 * wib + row;
+                    if (j < blk.n_zones && rl == 15) {
+                        const double tc = l.zT[j];
+                        const double cz = zone_mcp(l.zvol[j], tc);
+                        double a = l.zsa[j], b = l.zsb[j];
+                        gather(j, a, b);
+                        finish(j, a, b, tc, cz);
+                    }
                 }
             }
         }
