@@ -166,10 +166,18 @@ def run_case(seed):
         oracle.OracleModel(md).march(r2, w, a0, b0)
         return r2
     got = st.copy()
+    rng3 = np.random.default_rng(seed ^ 0x5e7f)
+    ts = None
+    if rng3.random() < 0.12:  # (a caller's stream — torch's, as heat_amd/sharded.py passes it — instead of the batch's own)
+        try:
+            import torch
+            ts = torch.cuda.Stream()
+            kw = dict(kw, stream=ts.cuda_stream)
+        except Exception:  # noqa
+            ts = None
     with HeatBatch(md, **kw) as b:
         b.upload_state(got)
         lo = 0
-        rng3 = np.random.default_rng(seed ^ 0x5e7f)
         for c in cuts:
             if c > lo:
                 if rng3.random() < 0.2:
