@@ -230,6 +230,11 @@ int check_desc(const heat_batch_desc *d, std::string &err) {
                 return failp(err, HEAT_E_SIZE, "surface %lld: cavity index out of range", (long long)s);
             if (!cav && std::isnan(d->uvalue[o + i]))
                 return failp(err, HEAT_E_UVALUE_NONE, "surface %lld node %lld: UValue::None", (long long)s, (long long)i);
+            // (a node is massive iff mass >= 1e-5, discretization.rs:149,155: a NaN is neither massive nor no-mass — the
+            // reference's chunks would silently leave the node out; here it is refused. Found by tools/fuzz_desc.py as an
+            // endless loop of the planner.)
+            if (std::isnan(d->mass[o + i]))
+                return failp(err, HEAT_E_INVALID_ARG, "surface %lld node %lld: thermal mass is NaN", (long long)s, (long long)i);
         }
     }
     return HEAT_OK;
