@@ -243,6 +243,11 @@ int check_desc(const heat_batch_desc *d, std::string &err) {
 int make_plan(const heat_batch_desc *d, const heat_batch_options &opt, Plan &p, std::string &err) {
     int rc = check_desc(d, err);
     if (rc) return rc;
+    // (heat_batch_create_ex refuses these before it comes here; heat_plan_check comes straight)
+    if (opt.nodes_per_lane != 0 && opt.nodes_per_lane != 4 && opt.nodes_per_lane != 8 && opt.nodes_per_lane != 16)
+        return failp(err, HEAT_E_INVALID_ARG, "nodes_per_lane must be 0, 4, 8 or 16");
+    if (opt.n_ranks > 1 && (opt.rank < 0 || opt.rank >= opt.n_ranks))
+        return failp(err, HEAT_E_INVALID_ARG, "rank %d outside [0, %d)", opt.rank, opt.n_ranks);
     const int64_t S = d->n_surfaces, Z = d->n_zones;
     p = Plan();
     p.n_surf = S;

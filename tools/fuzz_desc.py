@@ -38,10 +38,24 @@ while time.time() < t_end:
             a = np.array(md[k], dtype=np.float64).copy()
             a[int(rng.integers(0, len(a)))] = float(rng.choice([np.nan, np.inf, -np.inf, -1.0, 0.0, 1e300, -1e300, 1e-300]))
             md[k] = a
+        elif rng.random() < 0.5:
+            k = str(rng.choice(["n_state", "dt", "n_zones"]))
+            if k == "dt":
+                md[k] = [0, -1, 1, float("nan"), 1e300][int(rng.integers(0, 5))]
+            elif k == "n_state":
+                md[k] = int(rng.choice([0, -1, 1, 5]))
+            else:  # fewer zones than the surfaces name (the zone arrays keep their length)
+                md[k] = int(rng.choice([0, 1, max(0, int(md["n_zones"]) - 1)]))
         else:
-            k = str(rng.choice(["n_state", "dt"]))
-            md[k] = [0, -1, 1, float("nan"), 1e300][int(rng.integers(0, 5))] if k == "dt" else int(rng.choice([0, -1, 1, 5]))
-    opts = [dict(), dict(fuse_always=True), dict(no_fusion=True), dict(nodes_per_lane=int(rng.choice([4, 8, 16]))), dict(force_general=True)][int(rng.integers(0, 5))]
+            cav = md.get("cavities")
+            if cav is not None and len(cav):  # a gas cavity's record
+                f = str(rng.choice(["thickness", "height", "angle", "eout", "ein", "gas"]))
+                cav = cav.copy()
+                cav[f][int(rng.integers(0, len(cav)))] = (int(rng.choice([-1, 7, 2**31 - 1])) if f == "gas"
+                                                          else float(rng.choice([np.nan, 0.0, -1.0, np.inf, 1e300])))
+                md["cavities"] = cav
+    opts = [dict(), dict(fuse_always=True), dict(no_fusion=True), dict(nodes_per_lane=int(rng.choice([4, 8, 16, 5, -4, 64]))), dict(force_general=True),
+            dict(n_ranks=int(rng.choice([2, 0, -1])), rank=int(rng.choice([0, 1, 5, -1]))), dict(no_palette=True)][int(rng.integers(0, 7))]
     if os.environ.get("FUZZ_DESC_VERBOSE"):
         print("seed", seed, opts, flush=True)
     try:
