@@ -32,8 +32,23 @@ struct Discretization {
 
 // discretize_construction, :410-544 — the recursion `aux(.., n + 1, ..)` restarts the layer loop with a
 // finer timestep; written here as a loop over n.
+// What Discretization::new takes for granted (the reference loops for ever, or panics on an allocation, where these do not
+// hold): positive finite timesteps and element size, a refinement that ends within a million subdivisions, positive finite
+// thickness / conductivity / density / specific heat of every solid layer. Found by tools/fuzz_setup.py's damaged constructions.
+static bool positive(double x) { return x > 0.0 && std::isfinite(x); }
+int check_construction(int32_t n_layers, const heat_layer *layers, double model_dt, double max_dx, double min_dt) {
+    if (!positive(model_dt) || !positive(max_dx) || !positive(min_dt) || model_dt / min_dt > 1e6) return HEAT_E_INVALID_ARG;
+    for (int32_t l = 0; l < n_layers; l++) {
+        const heat_layer &L = layers[l];
+        if (!positive(L.thickness)) return HEAT_E_INVALID_ARG;
+        if (!L.is_gas && (!positive(L.conductivity) || !positive(L.density) || !positive(L.specific_heat))) return HEAT_E_INVALID_ARG;
+    }
+    return HEAT_OK;
+}
+
 int discretize(int32_t n_layers, const heat_layer *layers, double model_dt, double max_dx, double min_dt,
                int32_t *n_elements) {
+    if (int rc = check_construction(n_layers, layers, model_dt, max_dx, min_dt)) return rc;
     for (int n = 1;; n++) {
         const double dt = model_dt / static_cast<double>(n);
         const bool can_refine = model_dt / static_cast<double>(n + 1) > min_dt;
@@ -55,6 +70,7 @@ int discretize(int32_t n_layers, const heat_layer *layers, double model_dt, doub
                 else n_elements[l] = 0;
             } else {  // :480-502
                 const double m = std::floor(L.thickness / min_dx);
+                if (!(m >= 1.0 && m <= 1e6)) return HEAT_E_TOO_MANY_NODES;  // (a layer of more than a million elements)
                 const double dx = L.thickness / m;
                 if (dx > max_dx) {
                     if (can_refine) restart = true;
@@ -354,6 +370,7 @@ int heat_model_builder_finish(heat_model_builder *mb, const heat_batch_desc **de
             Discretization &d = s.d;
             d.n_elements.resize(nl);
             d.tstep_subdivision = discretize(nl, s.layers.data(), main_dt, max_dx, min_dt, d.n_elements.data());
+            if (d.tstep_subdivision < 0) return d.tstep_subdivision;
             const int32_t nn = count_nodes(nl, d.n_elements.data());
             d.mass.resize(nn);
             d.uvalue.resize(nn);

@@ -63,5 +63,10 @@ while time.time() < t_end:
         n_ok += 1
     except binding.HeatError:
         n_err += 1
+    if seed % 5 == 0:  # heat_partition on the damaged model, with sensible and senseless rank counts
+        try:
+            binding.partition(md, int(rng.choice([1, 2, 3, 8, 0, -2, 100000])), lib=L)
+        except binding.HeatError:
+            pass
     seed += 1
 print("fuzz_desc: %d damaged descriptors refused with an error code, %d planned (the damage was harmless), no crash; seeds up to %d" % (n_err, n_ok, seed - 1))

@@ -70,4 +70,42 @@ while time.time() < t_end:
     n += 1
     seed += 1
 print("fuzz_setup: %d constructions equal, %d rejected by both, %d differ" % (n, rejected, bad))
+
+# damaged constructions through the product's library alone: an error code or a result, never a crash or an endless loop
+# (a non-positive thickness or conductivity, NaN / infinite properties, a gas gap at a face, absurd timesteps)
+import signal
+def _alarm(*a):
+    raise TimeoutError("the setup library did not come back")
+signal.signal(signal.SIGALRM, _alarm)
+rng = np.random.default_rng(seed)
+n_dmg = n_refused = 0
+for _ in range(4000):
+    nl = int(rng.integers(1, 5))
+    layers = []
+    for i in range(nl):
+        if rng.random() < 0.2:
+            layers.append(dict(thickness=float(rng.choice([0.01, 0.0, -0.01, np.nan, 1e9])), is_gas=True, gas=int(rng.choice([mdl.AIR, mdl.ARGON, 7, -1]))))
+            continue
+        L = dict(thickness=float(rng.choice([0.1, 0.0, -1.0, np.nan, np.inf, 1e-12, 1e6])), k=float(rng.choice([1.0, 0.0, -1.0, np.nan, np.inf, 1e-300])),
+                 rho=float(rng.choice([1000., 0.0, -5.0, np.nan, 1e300])), cp=float(rng.choice([1000., 0.0, -1.0, np.nan, np.inf])))
+        if rng.random() < 0.3:
+            L.update(tau=float(rng.choice([0.5, -1.0, 2.0, np.nan])))
+        layers.append(L)
+    main_dt = float(rng.choice([600., 0.0, -1.0, np.nan, 1e-9, 1e12]))
+    max_dx = float(rng.choice([0.04, 0.0, -1.0, np.nan, 1e-12]))
+    min_dt = float(rng.choice([60., 0.0, -1.0, np.nan, 1e9]))
+    signal.alarm(20)
+    try:
+        binding.discretize(layers, main_dt, max_dx, min_dt, 1., float(rng.choice([0.7, np.nan, 1e9])))
+    except TimeoutError:
+        bad += 1
+        print("FAIL damaged construction hangs the setup library: %r main_dt %r max_dx %r min_dt %r" % (layers, main_dt, max_dx, min_dt), flush=True)
+    except MemoryError:
+        n_refused += 1
+    except Exception:  # noqa
+        n_refused += 1
+    finally:
+        signal.alarm(0)
+    n_dmg += 1
+print("fuzz_setup: %d damaged constructions answered (%d with an error), none hung or crashed" % (n_dmg, n_refused) if not bad else "fuzz_setup: FAILURES above")
 sys.exit(1 if bad else 0)
