@@ -633,7 +633,7 @@ class ModelBuilder:
             cv = np.zeros(d.n_cavities, dtype=CAVITY_DTYPE)
             C.memmove(cv.ctypes.data, d.cavities, cv.nbytes)
             md["cavities"] = cv
-        state = np.ctypeslib.as_array(ps, shape=(int(d.n_state),)).copy()
+        state = np.ctypeslib.as_array(ps, shape=(int(d.n_state),)).copy() if int(d.n_state) > 0 else np.zeros(0)
         return md, state, int(nsub.value)
 
     def surface_info(self, i):

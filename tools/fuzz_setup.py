@@ -108,4 +108,43 @@ for _ in range(4000):
         signal.alarm(0)
     n_dmg += 1
 print("fuzz_setup: %d damaged constructions answered (%d with an error), none hung or crashed" % (n_dmg, n_refused) if not bad else "fuzz_setup: FAILURES above")
+
+# the model builder (ThermalModel::new, model.rs:215-354) with damaged zones, surfaces and constructions: a model — which the
+# planner then takes or refuses — or an error code
+from heat_amd import ModelBuilder
+n_built = n_ref = 0
+for k in range(1500):
+    rng = np.random.default_rng(seed * 7919 + k)
+    try:
+        mb = ModelBuilder(int(rng.choice([20, 1, 60, 0, -3, 10**6])), int(rng.choice([-1, 0, 1, 2, 3, 5, 99, -7])))
+    except binding.HeatError:
+        n_ref += 1
+        continue
+    try:
+        for _ in range(int(rng.integers(0, 4))):
+            mb.add_zone(float(rng.choice([600., 0.0, -1.0, np.nan, 1e300])))
+        for _ in range(int(rng.integers(0, 6))):
+            layers = []
+            for i in range(int(rng.integers(0, 4))):
+                if rng.random() < 0.2:
+                    layers.append(dict(thickness=float(rng.choice([0.02, 0.0, np.nan])), is_gas=True, gas=int(rng.choice([mdl.AIR, 9]))))
+                else:
+                    layers.append(dict(thickness=float(rng.choice([0.2, 0.02, 0.0, -1., np.nan, 1e6])), k=float(rng.choice([0.8, 0.0, np.nan])),
+                                       rho=float(rng.choice([1700., 0.0, -1.])), cp=float(rng.choice([800., np.nan, 0.0]))))
+            mb.add_surface(layers, float(rng.choice([60., 0.0, -1., np.nan])), float(rng.choice([46., 0.0, np.nan])),
+                           [float(rng.choice([0., 1., np.nan])), float(rng.choice([-1., 0.])), float(rng.choice([0., 1., 2.]))],
+                           float(rng.choice([1.5, -1., np.nan, 1e9])), int(rng.choice([0, 1, 2, 3, -1, 9])), int(rng.choice([0, 1, 2, 3, -1])),
+                           front_zone=int(rng.choice([0, 1, 5, -1])), back_zone=int(rng.choice([0, 2, -3])),
+                           is_fenestration=bool(rng.random() < 0.3))
+        md_b, _, _ = mb.finish()
+        try:
+            binding.plan_check(md_b)
+        except binding.HeatError:
+            pass
+        n_built += 1
+    except binding.HeatError:
+        n_ref += 1
+    finally:
+        mb.close()
+print("fuzz_setup: model builder: %d damaged models refused, %d built, no crash" % (n_ref, n_built))
 sys.exit(1 if bad else 0)
