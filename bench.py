@@ -31,6 +31,10 @@ exchanged with an RCCL all-gather per sub-timestep on the library's own communic
 n_shared_zones, collective, comm_ranks (and collective_fallback when the native communicator could not be had on
 every rank). `--scaling weak` gives every rank a model of its own with zones shared across the rank boundaries.
 
+Before the W warmup steps of every leg the batch marches untimed for --settle-ms (60 ms; `settle` in the line): the chip needs
+20-30 ms of load to reach the clock it then holds (tools/settle.py: the headline's sub-timestep goes 69.8 -> 64.4 us over the
+first 25 ms, and is back at 71 after two idle seconds) — a timed region of one march call would otherwise measure that ramp.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline            the dominant kernel against the resource that bounds it. Streamed march: "hbm" — algorithmic
                       bytes / kernel time (HIP events on the kernel's stream) against 8 TB/s. Cluster-resident march:
@@ -38,6 +42,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
                       the f64 vector peak, 78.6 TFLOP/s; its `issue` sub-object keeps the issue-slot view (measured
                       instruction counts by class from the committed PMC passes x cycles per class) and is nulled,
                       with "counters_stale": true, when the committed counters were taken on other kernel sources;
+                      Streamed legs carry `kernel_us_rocprof` too (the kernels' mean durations in the committed trace of the
+                      same sources: HIP events around a two-kernel sub-timestep include the gap between its launches) and
+                      the `issue` view; BASELINE config 5, which moves a tenth of the bytes the chip could, names the
+                      instruction issue of its dependent chains as its bound ("valu_issue") and keeps the HBM figures beside;
   roofline_streaming  the streamed kernel's own line whenever the main run was cluster-resident;
   cpu_baseline        the CPU oracle (oracle/, a C port of the reference path) timed on this box's host cores on a
                       bounded sample of the same workload (rank 0, N = 1 only);
